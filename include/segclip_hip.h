@@ -1,0 +1,241 @@
+/* libsegclip_hip.so - C ABI of the MI355X (gfx950) SegCLIP hot-path kernels.
+ *
+ * Boundary contract:
+ *   - plain pointers + sizes, no torch / C++ types; every entry point is extern "C".
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates,
+ *     frees or retains device pointers and never synchronises the device.
+ *   - kernels are enqueued on the hipStream_t passed as `stream` (void*).
+ *   - return 0 on success, non-zero otherwise; segclip_last_error_string() describes the failure.
+ *   - stateless and re-entrant (forward thread + autograd thread may call concurrently).
+ *
+ * Each entry point replaces an *implicit* torch op group of the reference (the reference is pure
+ * Python and has no native interface of its own); the reference call site is cited per function
+ * (paths relative to the ArrowLuo/SegCLIP tree).
+ *
+ * dtypes: SEGCLIP_F32 activations run the exact-f32 MFMA path (v_mfma_f32_32x32x2_f32, parity
+ * gate 1e-3); SEGCLIP_BF16 activations run the bf16 MFMA path (v_mfma_f32_32x32x16_bf16,
+ * fp32 accumulate).  Parameters / gradients of parameters are always fp32.
+ */
+#ifndef SEGCLIP_HIP_H
+#define SEGCLIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGCLIP_ABI_VERSION 1
+
+#define SEGCLIP_F32 0
+#define SEGCLIP_BF16 1
+
+#define SEGCLIP_ACT_NONE 0
+#define SEGCLIP_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x), modules/module_clip_util.py:134-136 */
+#define SEGCLIP_ACT_GELU_ERF 2   /* nn.GELU(), modules/module_seg_vit.py:128 */
+
+#define SEGCLIP_ERR_INVALID (-1)
+#define SEGCLIP_ERR_UNSUPPORTED (-2)
+
+int segclip_version(void);
+const char* segclip_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue.   C[z](m,n) = epi( alpha * sum_k A[z](m,k) * B[z](n,k) )
+ *   epi(v): v += bias[n];  if act: (aux ? aux(m,n) = v : 0), v = act(v);   v += residual(m,n)
+ *   mul_dact: v = v * act'(aux(m,n))   (aux is an INPUT: the saved pre-activation; bias/residual unused)
+ * Replaces nn.Linear / MHA in-proj / out-proj / the einsum + Conv1d contractions:
+ *   modules/module_seg_vit.py:166-172,189,266-269,304,309 ; modules/module_clip_ttransformer.py:24-30 ;
+ *   modules/module_clip.py:91-94,131-134 ; modules/modeling.py:356-357 and their autograd backward
+ *   (dgrad: A = dY, B(n,k) = W^T via strides; wgrad: A = dY^T, B = X^T via strides).
+ * Operand strides are in elements.  f32 operands: any strides.  bf16 operands: each of A, B must
+ * have unit stride along k (sak == 1) or along its row index (sam == 1).  a_dtype may be F32 with
+ * b_dtype BF16 (fp32 residual-stream gradients are rounded to bf16 while staging).
+ * Batch index z = z1*nb2 + z2 with independent strides for both levels (heads / groups).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct segclip_gemm_desc {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;    /* [N] fp32 or NULL */
+  const void* residual; /* (M,N) leading dim ldr, dtype r_dtype, or NULL */
+  void* aux;            /* (M,N) leading dim ldaux, dtype c_dtype, or NULL */
+  int64_t M, N, K;
+  int64_t sam, sak;
+  int64_t sbn, sbk;
+  int64_t ldc, ldr, ldaux;
+  int64_t nb1, nb2;
+  int64_t bsA1, bsA2, bsB1, bsB2, bsC1, bsC2; /* aux uses the C batch strides */
+  int64_t bsR1, bsR2;                         /* residual batch strides (0 = broadcast over the batch) */
+  int32_t a_dtype, b_dtype, c_dtype, r_dtype;
+  int32_t act;
+  int32_t mul_dact;
+  float alpha;
+  int32_t reserved;
+  void* ws;         /* optional split-K scratch (bf16 path, plain epilogue only); NULL = no split-K */
+  int64_t ws_bytes; /* size of ws; segclip_gemm_ws_bytes(d) is the amount that enables split-K */
+} segclip_gemm_desc;
+
+size_t segclip_gemm_ws_bytes(const segclip_gemm_desc* d);
+int segclip_gemm(const segclip_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last axis (fp32 statistics).  modules/module_clip_util.py:126-132,
+ * modules/module_seg_vit.py:150-156 (eps 1e-5), modules/modeling.py:152 (eps 1e-6).
+ * bwd: dx = LN'(dy) (+ dres if given);  dgamma/dbeta (fp32, [cols]) are fully reduced.
+ * ws: segclip_layernorm_bwd_ws_bytes(rows, cols) bytes of scratch.
+ * ------------------------------------------------------------------------------------------ */
+int segclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, int64_t rows, int64_t cols, float eps, int x_dtype, int y_dtype,
+                          void* stream);
+size_t segclip_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols);
+int segclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                          const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                          void* ws, int64_t rows, int64_t cols, int dy_dtype, int x_dtype, int dx_dtype,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention core  O = softmax(scale * Q K^T [+ causal mask]) V,  head_dim <= 64.
+ * Replaces the inside of nn.MultiheadAttention: modules/module_seg_vit.py:189 (self, 12x64),
+ * :215 (center cross-attention; K/V addressed with explicit (batch, token) strides so that both
+ * the torch-1.8 "t18" buffer reinterpretation and the intended layout run on the same kernel,
+ * SURVEY.md finding 0.4), modules/module_clip_ttransformer.py:46 (causal, mask of
+ * modules/module_clip_util.py:199-205 generated in-kernel), modules/module_mae.py:124-130 (8x48).
+ * Element strides: *_sb batch, *_st token; head h lives at offset h*hd.
+ * stats: fp32 scratch kept for backward, segclip_attn_stats_bytes() bytes
+ *        (bf16: log-sum-exp per row; f32: the full probability matrix).
+ * bwd ws: segclip_attn_bwd_ws_bytes() bytes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct segclip_attn_desc {
+  const void* Q;
+  const void* K;
+  const void* V;
+  void* O;
+  void* stats;
+  const void* dO;
+  void* dQ;
+  void* dK;
+  void* dV;
+  void* ws;
+  int64_t B, H, Tq, Tk, hd;
+  int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
+  int64_t dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st, do_sb, do_st;
+  float scale;
+  int32_t causal;
+  int32_t dtype;
+  int32_t reserved;
+} segclip_attn_desc;
+
+size_t segclip_attn_stats_bytes(const segclip_attn_desc* d);
+size_t segclip_attn_bwd_ws_bytes(const segclip_attn_desc* d);
+int segclip_attn_fwd(const segclip_attn_desc* d, void* stream);
+int segclip_attn_bwd(const segclip_attn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / reduction helpers
+ * ------------------------------------------------------------------------------------------ */
+/* dst[i] = (dst_dtype) src[i] */
+int segclip_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* out[n] = sum_m X[m*ld + n]  (bias gradients; deterministic two-stage).  ws: colsum_ws_bytes */
+size_t segclip_colsum_ws_bytes(int64_t M, int64_t N);
+int segclip_colsum(const void* X, float* out, void* ws, int64_t M, int64_t N, int64_t ld, int dtype,
+                   void* stream);
+/* y = act(x) ; dx = dy * act'(x)  (stand-alone activation, modules/module_seg_vit.py:274,330) */
+int segclip_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
+int segclip_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype, void* stream);
+/* out = a + b (same dtype) */
+int segclip_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vision front end.  modules/module_clip_vtransformer.py:56-64.
+ * im2col: image (B,3,H,W) fp32 -> cols (B*gh*gw, 3*p*p), column order (c,py,px) [layout 0, conv1]
+ *         or (py,px,c) [layout 1, MAE target `patchify`, modules/module_mae.py:18-29].
+ * assemble: x[b,0,:] = cls + pos[0];  x[b,1+t,:] = patches[b,t,:] + pos[1+t]   (fp32 out)
+ * ------------------------------------------------------------------------------------------ */
+int segclip_im2col(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                   int layout, int out_dtype, void* stream);
+int segclip_vis_assemble(const void* patches, const float* cls, const float* pos, float* x, int64_t B,
+                         int64_t T, int64_t D, int p_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Text front end.  modules/module_clip.py:109-112 (nn.Embedding gather + positional add) and its
+ * backward (scatter-add into the fp32 table gradient, which must be zero-initialised by the caller;
+ * dpos (L,D) is fully written).
+ * ------------------------------------------------------------------------------------------ */
+int segclip_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* out, int64_t B,
+                      int64_t L, int64_t D, int64_t vocab, void* stream);
+int segclip_embed_bwd(const int64_t* ids, const float* dout, float* dtable, float* dpos, int64_t B,
+                      int64_t L, int64_t D, int64_t vocab, void* stream);
+
+/* Row gather / scatter-add with int64 indices (EOT pick modules/module_clip.py:136, MAE keep /
+ * un-shuffle gathers modules/module_clip_util.py:110, modules/module_mae.py:310).
+ * gather: out[b, j, :] = src[b, idx[b,j], :] ; scatter_add: dsrc[b, idx[b,j], :] += dout[b, j, :]
+ * (dsrc zero-initialised by the caller; indices within one b must be unique -> no atomics). */
+int segclip_gather_rows(const void* src, const int64_t* idx, void* out, int64_t B, int64_t Tsrc,
+                        int64_t Tout, int64_t D, int dtype, void* stream);
+int segclip_scatter_rows(const void* dout, const int64_t* idx, void* dsrc, int64_t B, int64_t Tsrc,
+                         int64_t Tout, int64_t D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Learnable-center hard assignment.  modules/module_seg_vit.py:304-310 + gumbel_softmax :221-242.
+ *   logits (B,G,T) fp32 = q k^T (un-scaled; computed by segclip_gemm in fp32 always)
+ *   training: y = softmax((logits + gumbel)/tau, dim=G);  eval (gumbel NULL): y = softmax(logits)
+ *   idx[b,t] = argmax_g y (first max wins, like torch.max);  hard = onehot(idx)
+ *   soft = softmax(logits, dim=G)   (consumed by the segmentation evaluation only)
+ *   counts[b,g] = max(sum_t hard, 1)
+ * bwd (straight-through): dlogits = dy_soft-path gradient of y given dhard (B,G,T):
+ *   dlogits[b,:,t] = (y * (dhard - sum_g dhard*y)) / tau
+ * ------------------------------------------------------------------------------------------ */
+int segclip_assign_fwd(const float* logits, const float* gumbel, float tau, float* y_soft, float* soft,
+                       uint8_t* idx, float* hard, float* counts, int64_t B, int64_t G, int64_t T,
+                       void* stream);
+int segclip_assign_bwd(const float* dhard, const float* y_soft, float tau, float* dlogits, int64_t B,
+                       int64_t G, int64_t T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses.
+ * l2norm: y = x / ||x||  rows (modules/modeling.py:341-345).
+ * ce: mean over rows of -log softmax(logits)[label], label = row + label_offset
+ *     (modules/modeling.py:205-209).  fwd writes loss (1 float) and lse per row; bwd writes
+ *     dlogits = gscale * (softmax - onehot) / rows.
+ * superpixel_kl: modules/modeling.py:212-224 on the hard assignment indices (label-histogram
+ *     formulation).  Output is a constant w.r.t. parameters only through hard's straight-through
+ *     gradient: bwd returns dhard (B,G,T).
+ * masked_mse: MAE loss modules/module_mae.py:323-328: pred (B,1+T,Dp) (row 0 = CLS, skipped),
+ *     target (B,T,Dp), mask (B,1+T).
+ * ------------------------------------------------------------------------------------------ */
+int segclip_l2norm_fwd(const float* x, float* y, float* norm, int64_t rows, int64_t cols, void* stream);
+int segclip_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int64_t rows,
+                       int64_t cols, void* stream);
+int segclip_ce_fwd(const float* logits, float* lse, float* loss_rows, int64_t rows, int64_t cols,
+                   int64_t label_offset, void* stream);
+/* dlogits = (*gscale_ptr) * gscale * (softmax - onehot) / rows ; gscale_ptr (device scalar, upstream
+ * gradient) may be NULL */
+int segclip_ce_bwd(const float* logits, const float* lse, const float* gscale_ptr, float gscale,
+                   float* dlogits, int64_t rows, int64_t cols, int64_t label_offset, void* stream);
+/* loss_rows[b] = this image's share of the loss (already / (2*B*T*G)); dhard = d(sum loss_rows)/dhard */
+int segclip_superpixel_kl(const float* hard, const int64_t* seg, float* loss_rows, float* dhard,
+                          int64_t B, int64_t G, int64_t T, void* stream);
+/* loss_rows[b*T+t] = mask[b,1+t] * mean_d (pred[b,1+t,d]-target[b,t,d])^2 ; loss = sum(loss_rows)/sum(mask[:,1:]) */
+int segclip_masked_mse_fwd(const void* pred, const float* target, const float* mask, float* loss_rows,
+                           int64_t B, int64_t T, int64_t Dp, int pred_dtype, void* stream);
+int segclip_masked_mse_bwd(const void* pred, const float* target, const float* mask,
+                           const float* gscale_ptr, const float* mask_sum, float gscale, void* dpred,
+                           int64_t B, int64_t T, int64_t Dp, int pred_dtype, void* stream);
+/* out[i] = x[i] * (*s)  (device scalar) ;  out[0] = scale * sum(x)  (deterministic single block) */
+int segclip_scale(const float* x, const float* s, float* out, int64_t n, void* stream);
+int segclip_reduce_sum(const float* x, float* out, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MAE random masking (integer path, bit-exact given the noise).  modules/module_clip_util.py:91-124
+ * with keep_cls: noise[:,0] = -1; ids_shuffle = argsort(noise) (stable); ids_restore =
+ * argsort(ids_shuffle); mask = 1 except the first len_keep of the shuffle.
+ * ------------------------------------------------------------------------------------------ */
+int segclip_mask_sort(const float* noise, int64_t* ids_shuffle, int64_t* ids_restore, float* mask,
+                      int64_t B, int64_t L, int64_t len_keep, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGCLIP_HIP_H */

@@ -129,47 +129,8 @@ def ensure_process_group(rank=0, world_size=1, port=29512):
 
 
 def synthetic_clip_state_dict(spec):
-    """Key/shape skeleton of an OpenAI-CLIP ViT state-dict (what CLIP.get_config would return,
-    modules/module_clip_util.py:174-197).  Values are zeros; callers overwrite every parameter."""
-    import torch
-    W, Wt, E = spec["vision_width"], spec["text_width"], spec["embed_dim"]
-    p, res = spec["patch"], spec["image_res"]
-    n = (res // p) ** 2 + 1
-    sd = {
-        "visual.conv1.weight": torch.zeros(W, 3, p, p),
-        "visual.class_embedding": torch.zeros(W),
-        "visual.positional_embedding": torch.zeros(n, W),
-        "visual.proj": torch.zeros(W, E),
-        "visual.ln_pre.weight": torch.ones(W), "visual.ln_pre.bias": torch.zeros(W),
-        "visual.ln_post.weight": torch.ones(W), "visual.ln_post.bias": torch.zeros(W),
-        "text_projection": torch.zeros(Wt, E),
-        "positional_embedding": torch.zeros(spec["context_length"], Wt),
-        "token_embedding.weight": torch.zeros(spec["vocab_size"], Wt),
-        "ln_final.weight": torch.ones(Wt), "ln_final.bias": torch.zeros(Wt),
-        "logit_scale": torch.tensor(float(np.log(1 / 0.07))),
-        "input_resolution": torch.tensor(res), "context_length": torch.tensor(spec["context_length"]),
-        "vocab_size": torch.tensor(spec["vocab_size"]),
-    }
-
-    def block(prefix, d):
-        sd[prefix + "attn.in_proj_weight"] = torch.zeros(3 * d, d)
-        sd[prefix + "attn.in_proj_bias"] = torch.zeros(3 * d)
-        sd[prefix + "attn.out_proj.weight"] = torch.zeros(d, d)
-        sd[prefix + "attn.out_proj.bias"] = torch.zeros(d)
-        sd[prefix + "ln_1.weight"] = torch.ones(d)
-        sd[prefix + "ln_1.bias"] = torch.zeros(d)
-        sd[prefix + "ln_2.weight"] = torch.ones(d)
-        sd[prefix + "ln_2.bias"] = torch.zeros(d)
-        sd[prefix + "mlp.c_fc.weight"] = torch.zeros(4 * d, d)
-        sd[prefix + "mlp.c_fc.bias"] = torch.zeros(4 * d)
-        sd[prefix + "mlp.c_proj.weight"] = torch.zeros(d, 4 * d)
-        sd[prefix + "mlp.c_proj.bias"] = torch.zeros(d)
-
-    for i in range(12):
-        block(f"visual.transformer.resblocks.{i}.", W)
-    for i in range(spec["text_layers"]):
-        block(f"transformer.resblocks.{i}.", Wt)
-    return sd
+    from segclip_amd.synth import synthetic_clip_state_dict as f
+    return f(spec)
 
 
 def build_reference_model(spec, flags, rank=0, world_size=1, cross_mode="t18"):

@@ -1,0 +1,138 @@
+"""ctypes binding of libsegclip_hip.so (include/segclip_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a kernel returns an
+error, a RuntimeError is raised.  Device pointers come from torch tensors (torch is used for memory
+and streams only); nothing of torch crosses the C ABI.
+"""
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsegclip_hip.so")
+_lib = None
+
+i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("residual", vp), ("aux", vp),
+                ("M", i64), ("N", i64), ("K", i64), ("sam", i64), ("sak", i64), ("sbn", i64), ("sbk", i64),
+                ("ldc", i64), ("ldr", i64), ("ldaux", i64), ("nb1", i64), ("nb2", i64),
+                ("bsA1", i64), ("bsA2", i64), ("bsB1", i64), ("bsB2", i64), ("bsC1", i64), ("bsC2", i64),
+                ("bsR1", i64), ("bsR2", i64),
+                ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("r_dtype", i32),
+                ("act", i32), ("mul_dact", i32), ("alpha", f32), ("reserved", i32),
+                ("ws", vp), ("ws_bytes", i64)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("stats", vp), ("dO", vp), ("dQ", vp), ("dK", vp),
+                ("dV", vp), ("ws", vp),
+                ("B", i64), ("H", i64), ("Tq", i64), ("Tk", i64), ("hd", i64),
+                ("q_sb", i64), ("q_st", i64), ("k_sb", i64), ("k_st", i64), ("v_sb", i64), ("v_st", i64),
+                ("o_sb", i64), ("o_st", i64),
+                ("dq_sb", i64), ("dq_st", i64), ("dk_sb", i64), ("dk_st", i64), ("dv_sb", i64), ("dv_st", i64),
+                ("do_sb", i64), ("do_st", i64),
+                ("scale", f32), ("causal", i32), ("dtype", i32), ("reserved", i32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/segclip_hip.h
+SIGNATURES = {
+    "segclip_version": (C.c_int, []),
+    "segclip_last_error_string": (C.c_char_p, []),
+    "segclip_gemm_ws_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "segclip_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "segclip_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),
+    "segclip_layernorm_bwd_ws_bytes": (C.c_size_t, [i64, i64]),
+    "segclip_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "segclip_attn_stats_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "segclip_attn_bwd_ws_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "segclip_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "segclip_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "segclip_cast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "segclip_colsum_ws_bytes": (C.c_size_t, [i64, i64]),
+    "segclip_colsum": (C.c_int, [vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "segclip_act_fwd": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "segclip_act_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, vp]),
+    "segclip_add": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
+    "segclip_scale": (C.c_int, [vp, vp, vp, i64, vp]),
+    "segclip_reduce_sum": (C.c_int, [vp, vp, i64, f32, vp]),
+    "segclip_im2col": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_int, C.c_int, vp]),
+    "segclip_vis_assemble": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "segclip_embed_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_embed_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
+    "segclip_scatter_rows": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
+    "segclip_assign_fwd": (C.c_int, [vp, vp, f32, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_assign_bwd": (C.c_int, [vp, vp, f32, vp, i64, i64, i64, vp]),
+    "segclip_l2norm_fwd": (C.c_int, [vp, vp, vp, i64, i64, vp]),
+    "segclip_l2norm_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, vp]),
+    "segclip_ce_fwd": (C.c_int, [vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_ce_bwd": (C.c_int, [vp, vp, vp, f32, vp, i64, i64, i64, vp]),
+    "segclip_superpixel_kl": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_masked_mse_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "segclip_masked_mse_bwd": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, i64, i64, i64, C.c_int, vp]),
+    "segclip_mask_sort": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it is absent: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"segclip_amd: {_LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or segclip_amd/csrc/build.sh (hipcc, gfx950). There is no CPU / PyTorch fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the .so is stale w.r.t. the header
+        fn.restype = res
+        fn.argtypes = args
+    if lib.segclip_version() != 1:
+        raise RuntimeError("segclip_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().segclip_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"segclip_hip {what} failed (rc={rc}): {msg}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"segclip_amd: unsupported dtype {t.dtype}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("segclip_amd: HIP kernels need device tensors (there is no CPU fallback); got a "
+                           f"{t.device} tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("segclip_amd: HIP kernels need device tensors (there is no CPU fallback); got a "
+                               f"{t.device} tensor")

@@ -1,0 +1,483 @@
+// Multi-head attention core, head_dim <= 64, arbitrary (batch, token) strides for Q/K/V/O.
+//
+// bf16 path (flash style, never materialises the score matrix in HBM):
+//   forward : block = (b, h, group of <=8 query tiles of 32 rows), one wave per query tile.  K/V of a
+//             256-key chunk are staged once in LDS (swizzled 128-B rows).  Each wave computes the
+//             *transposed* score tile S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so a lane owns one
+//             query row: the online-softmax max/sum are 16 in-lane ops + one cross-half shuffle.  P^T is
+//             fed straight back as the B operand of O^T = V^T P^T; the V^T fragment comes from the LDS
+//             transpose read ds_read_b64_tr_b16 with the key order permuted to match the accumulator
+//             layout, so P never leaves registers.
+//   backward: block = (b, h); Q, K, V, dO tiles in LDS (<=256 tokens each).  Pass A (wave owns a key
+//             tile) accumulates dK, dV; pass B (wave owns a query tile) accumulates dQ.  S and dP are
+//             recomputed in both passes (no atomics, deterministic).
+// f32 path (exact parity mode): S = scale*Q K^T, row softmax, O = P V as three launches of the f32 MFMA
+//   GEMM + a softmax kernel; P is kept for backward (5 GEMMs + one elementwise kernel).
+#include "common.h"
+
+int segclip_gemm_f32_launch(const segclip_gemm_desc* d, hipStream_t stream);
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int ROWB = 128;  // bytes per LDS row (64 bf16)
+
+// swizzled byte offset of element (row, col) in a [rows][64] bf16 LDS tile.
+// f = rotr3((row>>1)&7): ds_read_b128 of 16 rows is conflict-free, and the 4-row tr16 reads of a
+// 32-lane half land in disjoint banks.
+__device__ __forceinline__ int swz(int row, int col) {
+  const int t = (row >> 1) & 7;
+  const int f = ((t & 1) << 2) | (t >> 1);
+  return row * ROWB + ((((col >> 3) ^ f)) << 4) + ((col & 7) << 1);
+}
+
+// MFMA operand fragment, k-contiguous rows: lane l -> row rbase + (l&31), cols kc*16 + 8*(l>>5) .. +7
+__device__ __forceinline__ bf16x8_t frag_rows(const char* t, int rbase, int kc, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(t + swz(rbase + (lane & 31), kc * 16 + 8 * (lane >> 5)));
+}
+// MFMA operand fragment of the TRANSPOSED tile: lane l -> "row" = column cbase + (l&31) of the tile,
+// k = tile rows  rbase + 4*(l>>5) + {0,1,2,3, 8,9,10,11}   (the key order of the 32x32 accumulator)
+__device__ __forceinline__ bf16x8_t frag_tr(const char* t, int rbase, int cbase, int lane) {
+  const int g4 = lane >> 4, q = lane & 15;
+  const int row = rbase + 4 * (g4 >> 1) + (q >> 2);
+  const int col = cbase + 16 * (g4 & 1) + 4 * (q & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t + swz(row, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t + swz(row + 8, col)));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ bf16x8_t pack8(const float* p) {
+  s16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(p[j]);
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+// accumulator row index of register r for half h (32x32 tile)
+__device__ __forceinline__ int accrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// stage `nrows_pad` rows (zero-filled beyond nvalid / beyond hd) of X[row*st + d] into a swizzled tile
+__device__ __forceinline__ void stage_rows(char* tile, const bf16_t* __restrict__ X, int64_t st, int row0, int nvalid,
+                                           int nrows_pad, int hd, int tid, int nthreads) {
+  for (int idx = tid; idx < nrows_pad * 8; idx += nthreads) {
+    const int r = idx >> 3, c = idx & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < nvalid && c * 8 < hd) v = *reinterpret_cast<const u32x4*>(X + (int64_t)(row0 + r) * st + c * 8);
+    *reinterpret_cast<u32x4*>(tile + swz(r, c * 8)) = v;
+  }
+}
+
+struct FwdArgs {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* lse;
+  int H, Tq, Tk, hd;
+  int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
+  float scale; int causal;
+};
+
+constexpr int KCHUNK = 256;
+
+__global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * KCHUNK * ROWB];
+  char* Kt = smem;
+  char* Vt = smem + KCHUNK * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int q0 = (blockIdx.x * nw + wave) * 32;
+  const int li = lane & 31, lh = lane >> 5;
+  const bf16_t* Qp = a.Q + (int64_t)b * a.q_sb + (int64_t)h * a.hd;
+  const bf16_t* Kp = a.K + (int64_t)b * a.k_sb + (int64_t)h * a.hd;
+  const bf16_t* Vp = a.V + (int64_t)b * a.v_sb + (int64_t)h * a.hd;
+  const int qg = q0 + li;
+  const bool wave_active = q0 < a.Tq;
+
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    const int d = kc * 16 + 8 * lh;
+    if (qg < a.Tq && d < a.hd) v = *reinterpret_cast<const u32x4*>(Qp + (int64_t)qg * a.q_st + d);
+    qf[kc] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  for (int c0 = 0; c0 < a.Tk; c0 += KCHUNK) {
+    const int nvalid = a.Tk - c0 < KCHUNK ? a.Tk - c0 : KCHUNK;
+    const int npad = (nvalid + 31) & ~31;
+    __syncthreads();
+    stage_rows(Kt, Kp, a.k_st, c0, nvalid, npad, a.hd, tid, blockDim.x);
+    stage_rows(Vt, Vp, a.v_st, c0, nvalid, npad, a.hd, tid, blockDim.x);
+    __syncthreads();
+    if (!wave_active) continue;
+    for (int kt = 0; kt < npad; kt += 32) {
+      if (a.causal && c0 + kt > q0 + 31) break;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kt, kc, lane), qf[kc], s, 0, 0, 0);
+      float p[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = c0 + kt + accrow(r, lh);
+        const bool ok = key < a.Tk && (!a.causal || key <= qg);
+        p[r] = ok ? s[r] * a.scale : -INFINITY;
+        mx = fmaxf(mx, p[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float msafe = mn == -INFINITY ? 0.f : mn;
+      const float alpha = __expf(m - msafe);  // m = -inf -> 0
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { p[r] = __expf(p[r] - msafe); rs += p[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      const bf16x8_t pb0 = pack8(p), pb1 = pack8(p + 8);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt, dt * 32, lane), pb0, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt + 16, dt * 32, lane), pb1, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_active || qg >= a.Tq) return;
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  bf16_t* Op = a.O + (int64_t)b * a.o_sb + (int64_t)qg * a.o_st + (int64_t)h * a.hd;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = dt * 32 + 8 * rg + 4 * lh;
+      if (d < a.hd) {
+        u32x2 t;
+        t[0] = pack2bf(o[dt][rg * 4 + 0] * inv, o[dt][rg * 4 + 1] * inv);
+        t[1] = pack2bf(o[dt][rg * 4 + 2] * inv, o[dt][rg * 4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(Op + d) = t;
+      }
+    }
+  if (lh == 0) a.lse[((int64_t)b * a.H + h) * a.Tq + qg] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+}
+
+struct BwdArgs {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* O; const bf16_t* dO; const float* lse;
+  bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+  int H, Tq, Tk, hd;
+  int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, do_sb, do_st;
+  int64_t dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
+  float scale; int causal;
+};
+
+constexpr int TMAX = 256;
+
+__device__ __forceinline__ void store_acc_T(bf16_t* base, int64_t st, int row, int nrows, int hd, const f32x16 (&acc)[2],
+                                            int lh) {
+  if (row >= nrows) return;
+  bf16_t* p = base + (int64_t)row * st;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = dt * 32 + 8 * rg + 4 * lh;
+      if (d < hd) {
+        u32x2 t;
+        t[0] = pack2bf(acc[dt][rg * 4 + 0], acc[dt][rg * 4 + 1]);
+        t[1] = pack2bf(acc[dt][rg * 4 + 2], acc[dt][rg * 4 + 3]);
+        *reinterpret_cast<u32x2*>(p + d) = t;
+      }
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TMAX * ROWB + 2 * TMAX * 4];
+  char* Qt = smem;
+  char* Kt = smem + TMAX * ROWB;
+  char* Vt = smem + 2 * TMAX * ROWB;
+  char* Gt = smem + 3 * TMAX * ROWB;  // dO
+  float* Ls = reinterpret_cast<float*>(smem + 4 * TMAX * ROWB);
+  float* Ds = Ls + TMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t hoff = (int64_t)h * a.hd;
+  const bf16_t* Qp = a.Q + b * a.q_sb + hoff;
+  const bf16_t* Kp = a.K + b * a.k_sb + hoff;
+  const bf16_t* Vp = a.V + b * a.v_sb + hoff;
+  const bf16_t* Op = a.O + b * a.o_sb + hoff;
+  const bf16_t* Gp = a.dO + b * a.do_sb + hoff;
+  const int tqp = (a.Tq + 31) & ~31, tkp = (a.Tk + 31) & ~31;
+
+  stage_rows(Qt, Qp, a.q_st, 0, a.Tq, tqp, a.hd, tid, blockDim.x);
+  stage_rows(Kt, Kp, a.k_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
+  stage_rows(Vt, Vp, a.v_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
+  // dO tile + D[q] = sum_d dO*O (8 consecutive lanes share a row)
+  for (int idx = tid; idx < tqp * 8; idx += blockDim.x) {
+    const int r = idx >> 3, c = idx & 7;
+    u32x4 g = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
+    if (r < a.Tq && c * 8 < a.hd) {
+      g = *reinterpret_cast<const u32x4*>(Gp + (int64_t)r * a.do_st + c * 8);
+      ov = *reinterpret_cast<const u32x4*>(Op + (int64_t)r * a.o_st + c * 8);
+    }
+    *reinterpret_cast<u32x4*>(Gt + swz(r, c * 8)) = g;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s += __uint_as_float(g[j] << 16) * __uint_as_float(ov[j] << 16);
+      s += __uint_as_float(g[j] & 0xffff0000u) * __uint_as_float(ov[j] & 0xffff0000u);
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (c == 0) {
+      Ds[r] = s;
+      Ls[r] = r < a.Tq ? a.lse[((int64_t)b * a.H + h) * a.Tq + r] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---------------- pass A: this wave owns key tiles; dK, dV ----------------
+  for (int k0 = wave * 32; k0 < tkp; k0 += nw * 32) {
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) { kf[kc] = frag_rows(Kt, k0, kc, lane); vf[kc] = frag_rows(Vt, k0, kc, lane); }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    const int key = k0 + li;
+    for (int q0 = 0; q0 < tqp; q0 += 32) {
+      if (a.causal && q0 + 31 < k0) continue;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, q0, kc, lane), kf[kc], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gt, q0, kc, lane), vf[kc], dp, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + accrow(r, lh);
+        const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
+        const float pv = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - Ds[q]) * a.scale;
+      }
+      const bf16x8_t pb0 = pack8(p), pb1 = pack8(p + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gt, q0, dt * 32, lane), pb0, dv[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gt, q0 + 16, dt * 32, lane), pb1, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, q0, dt * 32, lane), sb0, dk[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, q0 + 16, dt * 32, lane), sb1, dk[dt], 0, 0, 0);
+      }
+    }
+    store_acc_T(a.dK + b * a.dk_sb + hoff, a.dk_st, key, a.Tk, a.hd, dk, lh);
+    store_acc_T(a.dV + b * a.dv_sb + hoff, a.dv_st, key, a.Tk, a.hd, dv, lh);
+  }
+
+  // ---------------- pass B: this wave owns query tiles; dQ ----------------
+  for (int q0 = wave * 32; q0 < tqp; q0 += nw * 32) {
+    bf16x8_t qf[4], gf[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) { qf[kc] = frag_rows(Qt, q0, kc, lane); gf[kc] = frag_rows(Gt, q0, kc, lane); }
+    const int q = q0 + li;
+    const float lq = Ls[q], dq_ = Ds[q];
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    for (int k0 = 0; k0 < tkp; k0 += 32) {
+      if (a.causal && k0 > q0 + 31) break;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, k0, kc, lane), qf[kc], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vt, k0, kc, lane), gf[kc], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + accrow(r, lh);
+        const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
+        const float pv = ok ? __expf(s[r] * a.scale - lq) : 0.f;
+        ds[r] = pv * (dp[r] - dq_) * a.scale;
+      }
+      const bf16x8_t sb0 = pack8(ds), sb1 = pack8(ds + 8);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, k0, dt * 32, lane), sb0, dq[dt], 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, k0 + 16, dt * 32, lane), sb1, dq[dt], 0, 0, 0);
+      }
+    }
+    store_acc_T(a.dQ + b * a.dq_sb + hoff, a.dq_st, q, a.Tq, a.hd, dq, lh);
+  }
+}
+
+// ------------------------------- f32 path helpers -------------------------------------------
+// in-place row softmax of S (rows = B*H*Tq, Tk cols), causal mask by query index row % Tq
+__global__ void softmax_rows_kernel(float* __restrict__ S, int64_t rows, int Tq, int Tk, int causal) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int q = (int)(row % Tq);
+  float* s = S + row * Tk;
+  const int lim = causal ? (q + 1 < Tk ? q + 1 : Tk) : Tk;
+  float mx = -INFINITY;
+  for (int c = lane; c < lim; c += 64) mx = fmaxf(mx, s[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < lim; c += 64) sum += expf(s[c] - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int c = lane; c < Tk; c += 64) s[c] = c < lim ? expf(s[c] - mx) * inv : 0.f;
+}
+// dS = P * (dP - sum_k dP*P) * scale, in place on dP
+__global__ void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, int64_t rows, int Tk,
+                                        float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = P + row * Tk;
+  float* d = dP + row * Tk;
+  float dot = 0.f;
+  for (int c = lane; c < Tk; c += 64) dot += p[c] * d[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < Tk; c += 64) d[c] = p[c] * (d[c] - dot) * scale;
+}
+
+void base_gemm(segclip_gemm_desc& g, const segclip_attn_desc* d) {
+  g = segclip_gemm_desc{};
+  g.nb1 = d->B; g.nb2 = d->H;
+  g.a_dtype = g.b_dtype = g.c_dtype = g.r_dtype = SEGCLIP_F32;
+  g.alpha = 1.f;
+}
+
+bool bf16_ok(const segclip_attn_desc* d) {
+  const int64_t s[] = {d->q_sb, d->q_st, d->k_sb, d->k_st, d->v_sb, d->v_st, d->o_sb, d->o_st};
+  for (int64_t v : s) if (v % 8) return false;
+  return d->hd % 8 == 0 && d->hd <= 64;
+}
+
+}  // namespace
+
+extern "C" size_t segclip_attn_stats_bytes(const segclip_attn_desc* d) {
+  if (d->dtype == SEGCLIP_BF16) return (size_t)d->B * d->H * d->Tq * sizeof(float);
+  return (size_t)d->B * d->H * d->Tq * d->Tk * sizeof(float);
+}
+extern "C" size_t segclip_attn_bwd_ws_bytes(const segclip_attn_desc* d) {
+  if (d->dtype == SEGCLIP_BF16) return 0;
+  return (size_t)d->B * d->H * d->Tq * d->Tk * sizeof(float);
+}
+
+extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGCLIP_REQUIRE(d->hd <= 64 && d->hd > 0, "attn: head_dim %lld unsupported (<=64)", (long long)d->hd);
+  SEGCLIP_REQUIRE(d->stats != nullptr, "attn_fwd: stats buffer required");
+  if (d->B == 0 || d->Tq == 0) return 0;
+  if (d->dtype == SEGCLIP_BF16) {
+    SEGCLIP_REQUIRE(bf16_ok(d), "attn_fwd bf16: head_dim and all strides must be multiples of 8");
+    FwdArgs a;
+    a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.V = (const bf16_t*)d->V; a.O = (bf16_t*)d->O;
+    a.lse = (float*)d->stats;
+    a.H = (int)d->H; a.Tq = (int)d->Tq; a.Tk = (int)d->Tk; a.hd = (int)d->hd;
+    a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st;
+    a.o_sb = d->o_sb; a.o_st = d->o_st; a.scale = d->scale; a.causal = d->causal;
+    const int tiles = (int)cdiv(d->Tq, 32);
+    const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
+    SEGCLIP_REQUIRE(d->B * d->H <= 65535, "attn_fwd: B*H too large");
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3((unsigned)cdiv(tiles, nw), (unsigned)(d->B * d->H)), dim3(nw * 64), 0,
+                       stream, a);
+    SEGCLIP_CHECK_LAUNCH("attn_fwd_bf16");
+    return 0;
+  }
+  // f32: S -> stats, softmax in place, O = P V
+  float* P = (float*)d->stats;
+  segclip_gemm_desc g;
+  base_gemm(g, d);
+  g.A = d->Q; g.B = d->K; g.C = P; g.M = d->Tq; g.N = d->Tk; g.K = d->hd;
+  g.sam = d->q_st; g.sak = 1; g.sbn = d->k_st; g.sbk = 1; g.ldc = d->Tk;
+  g.bsA1 = d->q_sb; g.bsA2 = d->hd; g.bsB1 = d->k_sb; g.bsB2 = d->hd;
+  g.bsC1 = d->H * d->Tq * d->Tk; g.bsC2 = d->Tq * d->Tk; g.alpha = d->scale;
+  int rc = segclip_gemm_f32_launch(&g, stream);
+  if (rc) return rc;
+  const int64_t rows = d->B * d->H * d->Tq;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, P, rows, (int)d->Tq,
+                     (int)d->Tk, d->causal);
+  SEGCLIP_CHECK_LAUNCH("attn_softmax_rows");
+  base_gemm(g, d);
+  g.A = P; g.B = d->V; g.C = d->O; g.M = d->Tq; g.N = d->hd; g.K = d->Tk;
+  g.sam = d->Tk; g.sak = 1; g.sbn = 1; g.sbk = d->v_st; g.ldc = d->o_st;
+  g.bsA1 = d->H * d->Tq * d->Tk; g.bsA2 = d->Tq * d->Tk; g.bsB1 = d->v_sb; g.bsB2 = d->hd;
+  g.bsC1 = d->o_sb; g.bsC2 = d->hd;
+  return segclip_gemm_f32_launch(&g, stream);
+}
+
+extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGCLIP_REQUIRE(d->hd <= 64 && d->hd > 0, "attn: head_dim %lld unsupported (<=64)", (long long)d->hd);
+  if (d->B == 0 || d->Tq == 0) return 0;
+  if (d->dtype == SEGCLIP_BF16) {
+    SEGCLIP_REQUIRE(bf16_ok(d), "attn_bwd bf16: head_dim and all strides must be multiples of 8");
+    const int64_t s[] = {d->dq_sb, d->dq_st, d->dk_sb, d->dk_st, d->dv_sb, d->dv_st, d->do_sb, d->do_st};
+    for (int64_t v : s) SEGCLIP_REQUIRE(v % 8 == 0, "attn_bwd bf16: gradient strides must be multiples of 8");
+    SEGCLIP_REQUIRE(d->Tq <= TMAX && d->Tk <= TMAX, "attn_bwd bf16: Tq=%lld Tk=%lld > %d not supported yet",
+                    (long long)d->Tq, (long long)d->Tk, TMAX);
+    BwdArgs a;
+    a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.V = (const bf16_t*)d->V; a.O = (const bf16_t*)d->O;
+    a.dO = (const bf16_t*)d->dO; a.lse = (const float*)d->stats;
+    a.dQ = (bf16_t*)d->dQ; a.dK = (bf16_t*)d->dK; a.dV = (bf16_t*)d->dV;
+    a.H = (int)d->H; a.Tq = (int)d->Tq; a.Tk = (int)d->Tk; a.hd = (int)d->hd;
+    a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st;
+    a.o_sb = d->o_sb; a.o_st = d->o_st; a.do_sb = d->do_sb; a.do_st = d->do_st;
+    a.dq_sb = d->dq_sb; a.dq_st = d->dq_st; a.dk_sb = d->dk_sb; a.dk_st = d->dk_st; a.dv_sb = d->dv_sb; a.dv_st = d->dv_st;
+    a.scale = d->scale; a.causal = d->causal;
+    const int tiles = (int)cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32);
+    const int nw = tiles < 8 ? tiles : 8;
+    hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(d->B * d->H)), dim3(nw * 64), 0, stream, a);
+    SEGCLIP_CHECK_LAUNCH("attn_bwd_bf16");
+    return 0;
+  }
+  SEGCLIP_REQUIRE(d->ws != nullptr, "attn_bwd f32: workspace required");
+  const float* P = (const float*)d->stats;
+  float* dP = (float*)d->ws;
+  const int64_t pz1 = d->H * d->Tq * d->Tk, pz2 = d->Tq * d->Tk;
+  segclip_gemm_desc g;
+  int rc;
+  // dV(key,d) = sum_q P[q][key] dO[q][d]
+  base_gemm(g, d);
+  g.A = P; g.B = d->dO; g.C = d->dV; g.M = d->Tk; g.N = d->hd; g.K = d->Tq;
+  g.sam = 1; g.sak = d->Tk; g.sbn = 1; g.sbk = d->do_st; g.ldc = d->dv_st;
+  g.bsA1 = pz1; g.bsA2 = pz2; g.bsB1 = d->do_sb; g.bsB2 = d->hd; g.bsC1 = d->dv_sb; g.bsC2 = d->hd;
+  if ((rc = segclip_gemm_f32_launch(&g, stream))) return rc;
+  // dP[q][key] = sum_d dO[q][d] V[key][d]
+  base_gemm(g, d);
+  g.A = d->dO; g.B = d->V; g.C = dP; g.M = d->Tq; g.N = d->Tk; g.K = d->hd;
+  g.sam = d->do_st; g.sak = 1; g.sbn = d->v_st; g.sbk = 1; g.ldc = d->Tk;
+  g.bsA1 = d->do_sb; g.bsA2 = d->hd; g.bsB1 = d->v_sb; g.bsB2 = d->hd; g.bsC1 = pz1; g.bsC2 = pz2;
+  if ((rc = segclip_gemm_f32_launch(&g, stream))) return rc;
+  const int64_t rows = d->B * d->H * d->Tq;
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, P, dP, rows,
+                     (int)d->Tk, d->scale);
+  SEGCLIP_CHECK_LAUNCH("attn_softmax_bwd_rows");
+  // dQ[q][d] = sum_key dS[q][key] K[key][d]
+  base_gemm(g, d);
+  g.A = dP; g.B = d->K; g.C = d->dQ; g.M = d->Tq; g.N = d->hd; g.K = d->Tk;
+  g.sam = d->Tk; g.sak = 1; g.sbn = 1; g.sbk = d->k_st; g.ldc = d->dq_st;
+  g.bsA1 = pz1; g.bsA2 = pz2; g.bsB1 = d->k_sb; g.bsB2 = d->hd; g.bsC1 = d->dq_sb; g.bsC2 = d->hd;
+  if ((rc = segclip_gemm_f32_launch(&g, stream))) return rc;
+  // dK[key][d] = sum_q dS[q][key] Q[q][d]
+  base_gemm(g, d);
+  g.A = dP; g.B = d->Q; g.C = d->dK; g.M = d->Tk; g.N = d->hd; g.K = d->Tq;
+  g.sam = 1; g.sak = d->Tk; g.sbn = 1; g.sbk = d->q_st; g.ldc = d->dk_st;
+  g.bsA1 = pz1; g.bsA2 = pz2; g.bsB1 = d->q_sb; g.bsB2 = d->hd; g.bsC1 = d->dk_sb; g.bsC2 = d->hd;
+  return segclip_gemm_f32_launch(&g, stream);
+}

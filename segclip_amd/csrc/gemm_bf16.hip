@@ -1,0 +1,365 @@
+// bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate) with fused epilogue.
+// C[z](m,n) = epi(alpha * sum_k A(m,k) * B(n,k)).
+//
+// One kernel template covers the three layouts of a training step:
+//   forward  Y = X W^T      : A k-contiguous, B k-contiguous          <A_KS=0, B_KS=0>
+//   dgrad    dX = dY W      : A k-contiguous, B k-strided (W[n][k])   <A_KS=0, B_KS=1>
+//   wgrad    dW = dY^T X    : A k-strided,   B k-strided             <A_KS=1, B_KS=1>
+// k-contiguous operands are staged as a [128 rows][64 k] LDS image (16-B chunk index XOR
+// ((row>>1)&7): conflict-free ds_read_b128 for the 32x32x16 fragment).  k-strided operands are
+// staged as [64 k][128 rows] (pitch 160) and the fragment is built with the gfx950 LDS
+// transpose read ds_read_b64_tr_b16, so neither W nor the activations are ever transposed in HBM.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 acc VGPRs).
+// Register-staged double buffer: global loads of tile t+1 are issued before the MFMAs of tile t and
+// written to the other LDS buffer afterwards (one barrier per K-step).  Workgroup ids are remapped so
+// each XCD walks a contiguous run of tiles (shared A panel stays in that XCD's L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+constexpr int KS_PITCH = 160;                 // elements per k-row of a k-strided image (320 B)
+constexpr int SZ_DIRECT = BM * BK * 2;        // 16384 B
+constexpr int SZ_KS = BK * KS_PITCH * 2;      // 20480 B
+
+struct Args {
+  const void* A; const bf16_t* B; void* C;
+  const float* bias; const void* residual; void* aux;
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
+  int64_t nb2, bsA1, bsA2, bsB1, bsB2, bsC1, bsC2, bsR1, bsR2;
+  int c_dtype, r_dtype, act, mul_dact; float alpha;
+  int nbx, nby;
+  int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
+};
+
+struct Stage { u32x4 v[4]; };
+
+// ---- global -> registers --------------------------------------------------------------------
+// k-contiguous operand: X(row,k) = X[row*ld + k]; thread -> chunk c = tid&7 (8 k), rows tid>>3 + 32*i
+template <typename T>
+__device__ __forceinline__ void gload_direct(Stage& s, const T* __restrict__ X, int64_t ld, int64_t row0,
+                                             int64_t nrows, int64_t k0, int64_t K, int tid) {
+  const int c = tid & 7;
+  const int64_t k = k0 + c * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = row0 + (tid >> 3) + 32 * i;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < nrows && k < K) {
+      const T* p = X + r * ld + k;
+      if constexpr (sizeof(T) == 2) {
+        if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+          v = *reinterpret_cast<const u32x4*>(p);
+        } else {
+          bf16_t e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (k + j < K) ? reinterpret_cast<const bf16_t*>(p)[j] : (bf16_t)0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+        }
+      } else {
+        float e[8];
+        if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+          e[0] = a[0]; e[1] = a[1]; e[2] = a[2]; e[3] = a[3]; e[4] = b[0]; e[5] = b[1]; e[6] = b[2]; e[7] = b[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (k + j < K) ? (float)p[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pack2bf(e[2 * j], e[2 * j + 1]);
+      }
+    }
+    s.v[i] = v;
+  }
+}
+
+// k-strided operand: X(row,k) = X[k*ld + row]; thread -> chunk c = tid&15 (8 rows), k = tid>>4 + 16*i
+template <typename T>
+__device__ __forceinline__ void gload_ks(Stage& s, const T* __restrict__ X, int64_t ld, int64_t row0,
+                                         int64_t nrows, int64_t k0, int64_t K, int tid) {
+  const int c = tid & 15;
+  const int64_t r = row0 + c * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t k = k0 + (tid >> 4) + 16 * i;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k < K && r < nrows) {
+      const T* p = X + k * ld + r;
+      if constexpr (sizeof(T) == 2) {
+        if (r + 8 <= nrows && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+          v = *reinterpret_cast<const u32x4*>(p);
+        } else {
+          bf16_t e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (r + j < nrows) ? reinterpret_cast<const bf16_t*>(p)[j] : (bf16_t)0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+        }
+      } else {
+        float e[8];
+        if (r + 8 <= nrows && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+          e[0] = a[0]; e[1] = a[1]; e[2] = a[2]; e[3] = a[3]; e[4] = b[0]; e[5] = b[1]; e[6] = b[2]; e[7] = b[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (r + j < nrows) ? (float)p[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pack2bf(e[2 * j], e[2 * j + 1]);
+      }
+    }
+    s.v[i] = v;
+  }
+}
+
+// ---- registers -> LDS -----------------------------------------------------------------------
+__device__ __forceinline__ void sstore_direct(const Stage& s, char* lds, int tid) {
+  const int c = tid & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    *reinterpret_cast<u32x4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = s.v[i];
+  }
+}
+__device__ __forceinline__ void sstore_ks(const Stage& s, char* lds, int tid) {
+  const int c = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (tid >> 4) + 16 * i;
+    *reinterpret_cast<u32x4*>(lds + k * (KS_PITCH * 2) + c * 16) = s.v[i];
+  }
+}
+
+// ---- LDS -> MFMA fragments ------------------------------------------------------------------
+// fragment of the 32-row sub-tile starting at `rbase`, k16-chunk kc: lane l -> row l&31, k = 8*(l>>5)+0..7
+__device__ __forceinline__ bf16x8_t frag_direct(const char* lds, int rbase, int kc, int lane) {
+  const int r = rbase + (lane & 31);
+  const int c = kc * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8_t*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+}
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8_t frag_ks(const char* lds, int rbase, int kc, int lane) {
+  // ds_read_b64_tr_b16: within each 16-lane group, lane q supplies the address of 4 contiguous
+  // b16 of k-row (q>>2); lane q receives column q of the 4x16 block -> 4 consecutive k for its row.
+  const int g4 = lane >> 4, q = lane & 15;
+  const int krow = kc * 16 + 8 * (g4 >> 1) + (q >> 2);
+  const int col = rbase + 16 * (g4 & 1) + 4 * (q & 3);
+  const char* p = lds + krow * (KS_PITCH * 2) + col * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * (KS_PITCH * 2)));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <bool A_KS, bool B_KS, bool A_F32>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
+  constexpr int SZA = A_KS ? SZ_KS : SZ_DIRECT;
+  constexpr int SZB = B_KS ? SZ_KS : SZ_DIRECT;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (SZA + SZB)];
+  using TA = typename std::conditional<A_F32, float, bf16_t>::type;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware bijective remap of the workgroup id (block b runs on XCD b%8)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t n0 = (int64_t)(wg % g.nbx) * BN, m0 = (int64_t)(wg / g.nbx) * BM;
+  const int64_t z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
+  const TA* A = reinterpret_cast<const TA*>(g.A) + z1 * g.bsA1 + z2 * g.bsA2;
+  const bf16_t* B = g.B + z1 * g.bsB1 + z2 * g.bsB2;
+  const int64_t coff = z1 * g.bsC1 + z2 * g.bsC2;
+  const int64_t roff = z1 * g.bsR1 + z2 * g.bsR2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stage sa, sb;
+  auto gload = [&](int64_t k0) {
+    if constexpr (A_KS) gload_ks<TA>(sa, A, g.lda, m0, g.M, k0, g.K, tid);
+    else gload_direct<TA>(sa, A, g.lda, m0, g.M, k0, g.K, tid);
+    if constexpr (B_KS) gload_ks<bf16_t>(sb, B, g.ldb, n0, g.N, k0, g.K, tid);
+    else gload_direct<bf16_t>(sb, B, g.ldb, n0, g.N, k0, g.K, tid);
+  };
+  auto sstore = [&](int buf) {
+    char* la = smem + buf * (SZA + SZB);
+    char* lb = la + SZA;
+    if constexpr (A_KS) sstore_ks(sa, la, tid); else sstore_direct(sa, la, tid);
+    if constexpr (B_KS) sstore_ks(sb, lb, tid); else sstore_direct(sb, lb, tid);
+  };
+
+  const int64_t kbeg = (int64_t)blockIdx.y * g.kper;
+  const int64_t kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+  const int64_t nk = (kend - kbeg + BK - 1) / BK;
+  const int64_t Kreal = g.K;
+  g.K = kend;  // loaders zero-fill k >= g.K
+  gload(kbeg);
+  sstore(0);
+  __syncthreads();
+  for (int64_t t = 0; t < nk; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < nk) gload(kbeg + (t + 1) * BK);
+    const char* la = smem + buf * (SZA + SZB);
+    const char* lb = la + SZA;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = A_KS ? frag_ks(la, wm * 64 + i * 32, kc, lane) : frag_direct(la, wm * 64 + i * 32, kc, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = B_KS ? frag_ks(lb, wn * 64 + j * 32, kc, lane) : frag_direct(lb, wn * 64 + j * 32, kc, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int li = lane & 31, lk = lane >> 5;
+  (void)Kreal;
+  if (g.splits > 1) {
+    float* slab = g.slab + ((int64_t)blockIdx.y * gridDim.z + z) * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t n = n0 + wn * 64 + j * 32 + li;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (m < g.M) slab[m * g.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + li;
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= g.M) continue;
+        float v = g.alpha * acc[i][j][r];
+        if (g.mul_dact) {
+          const int64_t o = coff + m * g.ldaux + n;
+          const float u = g.c_dtype == SEGCLIP_BF16 ? bf2f(((const bf16_t*)g.aux)[o]) : ((const float*)g.aux)[o];
+          v *= apply_act_grad(g.act, u);
+        } else {
+          v += bv;
+          if (g.act != SEGCLIP_ACT_NONE) {
+            if (g.aux) {
+              const int64_t o = coff + m * g.ldaux + n;
+              if (g.c_dtype == SEGCLIP_BF16) ((bf16_t*)g.aux)[o] = f2bf(v); else ((float*)g.aux)[o] = v;
+            }
+            v = apply_act(g.act, v);
+          }
+          if (g.residual) {
+            const int64_t o = roff + m * g.ldr + n;
+            v += g.r_dtype == SEGCLIP_BF16 ? bf2f(((const bf16_t*)g.residual)[o]) : ((const float*)g.residual)[o];
+          }
+        }
+        const int64_t o = coff + m * g.ldc + n;
+        if (g.c_dtype == SEGCLIP_BF16) ((bf16_t*)g.C)[o] = f2bf(v); else ((float*)g.C)[o] = v;
+      }
+    }
+}
+
+// C = alpha * sum_s slab[s]  (split-K combine; deterministic order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, int64_t M, int64_t N, int64_t ldc,
+                                     int64_t nb2, int64_t bsC1, int64_t bsC2, int splits, int64_t nz, float alpha,
+                                     int c_dtype) {
+  const int64_t total = nz * M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * total + i];
+    v *= alpha;
+    const int64_t z = i / (M * N), rem = i % (M * N), m = rem / N, n = rem % N;
+    const int64_t o = (z / nb2) * bsC1 + (z % nb2) * bsC2 + m * ldc + n;
+    if (c_dtype == SEGCLIP_BF16) ((bf16_t*)C)[o] = f2bf(v); else ((float*)C)[o] = v;
+  }
+}
+
+}  // namespace
+
+static int choose_splits(const segclip_gemm_desc* d) {
+  if (d->bias || d->residual || d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact) return 1;
+  const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
+  const int64_t tiles = cdiv(d->M, BM) * cdiv(d->N, BN) * nb;
+  const int64_t ksteps = cdiv(d->K, BK);
+  if (tiles >= 384 || ksteps < 16) return 1;
+  int64_t s = cdiv(768, tiles);
+  if (s > ksteps / 4) s = ksteps / 4;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : (int)s;
+}
+
+size_t segclip_gemm_bf16_ws_bytes(const segclip_gemm_desc* d) {
+  const int s = choose_splits(d);
+  if (s <= 1) return 0;
+  const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
+  return (size_t)s * nb * d->M * d->N * sizeof(float);
+}
+
+int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
+  const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
+  SEGCLIP_REQUIRE(!a_ks || d->sam == 1, "gemm_bf16: A needs unit stride along k or m (sam=%lld sak=%lld)",
+                  (long long)d->sam, (long long)d->sak);
+  SEGCLIP_REQUIRE(!b_ks || d->sbn == 1, "gemm_bf16: B needs unit stride along k or n (sbn=%lld sbk=%lld)",
+                  (long long)d->sbn, (long long)d->sbk);
+  SEGCLIP_REQUIRE(d->b_dtype == SEGCLIP_BF16, "gemm_bf16: B must be bf16");
+  Args g;
+  g.A = d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = d->bias; g.residual = d->residual; g.aux = d->aux;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.lda = a_ks ? d->sak : d->sam; g.ldb = b_ks ? d->sbk : d->sbn;
+  g.ldc = d->ldc; g.ldr = d->ldr; g.ldaux = d->ldaux;
+  g.nb2 = d->nb2 > 0 ? d->nb2 : 1;
+  g.bsA1 = d->bsA1; g.bsA2 = d->bsA2; g.bsB1 = d->bsB1; g.bsB2 = d->bsB2; g.bsC1 = d->bsC1; g.bsC2 = d->bsC2; g.bsR1 = d->bsR1; g.bsR2 = d->bsR2;
+  g.c_dtype = d->c_dtype; g.r_dtype = d->r_dtype; g.act = d->act; g.mul_dact = d->mul_dact; g.alpha = d->alpha;
+  g.nbx = (int)cdiv(d->N, BN); g.nby = (int)cdiv(d->M, BM);
+  const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * g.nb2;
+  SEGCLIP_REQUIRE(nb <= 65535, "gemm_bf16: batch too large (%lld)", (long long)nb);
+  g.splits = choose_splits(d);
+  if (g.splits > 1 && (d->ws == nullptr || (size_t)d->ws_bytes < segclip_gemm_bf16_ws_bytes(d))) g.splits = 1;
+  g.kper = g.splits > 1 ? cdiv(cdiv(d->K, BK), g.splits) * BK : d->K;
+  if (g.splits > 1) g.splits = (int)cdiv(d->K, g.kper);
+  g.slab = (float*)d->ws;
+  dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
+  const bool a_f32 = d->a_dtype == SEGCLIP_F32;
+#define LAUNCH(AK, BKS, AF) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, AF>), grid, dim3(NT), 0, stream, g)
+  if (!a_ks && !b_ks) { if (a_f32) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+  else if (!a_ks && b_ks) { if (a_f32) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+  else if (a_ks && b_ks) { if (a_f32) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+  else { if (a_f32) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+#undef LAUNCH
+  SEGCLIP_CHECK_LAUNCH("gemm_bf16");
+  if (g.splits > 1) {
+    const int64_t total = nb * d->M * d->N;
+    const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->ws, d->C, d->M,
+                       d->N, d->ldc, g.nb2, d->bsC1, d->bsC2, g.splits, nb, d->alpha, d->c_dtype);
+    SEGCLIP_CHECK_LAUNCH("splitk_reduce");
+  }
+  return 0;
+}

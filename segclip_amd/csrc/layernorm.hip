@@ -1,0 +1,218 @@
+// LayerNorm forward / backward (HBM-bound).  One wave per row, the row lives in registers
+// (cols <= 2048), fp32 statistics, 16-byte (fp32) / 8-byte (bf16) vector loads, wave shuffles for the
+// two reductions.  Backward fuses the residual-gradient add (dx = LN'(dy) + dres) and produces
+// dgamma/dbeta through a deterministic two-stage reduction (per-block partials -> column sums).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 8;          // float4 slots per lane -> cols <= 8*4*64 = 2048
+constexpr int WAVES = 4;         // rows per block iteration
+
+__device__ __forceinline__ f32x4 load4(const void* base, int dtype, int64_t idx) {
+  f32x4 r;
+  if (dtype == SEGCLIP_F32) {
+    r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+  } else {
+    const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(base) + idx);
+    r[0] = __uint_as_float(t[0] << 16); r[1] = __uint_as_float(t[0] & 0xffff0000u);
+    r[2] = __uint_as_float(t[1] << 16); r[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+  return r;
+}
+__device__ __forceinline__ void store4(void* base, int dtype, int64_t idx, f32x4 v) {
+  if (dtype == SEGCLIP_F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+  } else {
+    u32x2 t;
+    t[0] = pack2bf(v[0], v[1]); t[1] = pack2bf(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(base) + idx) = t;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, void* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int64_t rows, int cols, float eps, int xd, int yd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int nv = NV;
+  for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < rows; row += (int64_t)gridDim.x * WAVES) {
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (i < nv && c < cols) {
+        v[i] = load4(x, xd, row * cols + c);
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+      } else {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mu = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (i < nv && c < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / cols + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (i < nv && c < cols) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+        store4(y, yd, row * cols + c, o);
+      }
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const void* __restrict__ dres, void* __restrict__ dx,
+                                                            float* __restrict__ part, int64_t rows, int cols, int dyd,
+                                                            int xd, int dxd) {
+  __shared__ float red[WAVES][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int nv = NV;
+  f32x4 ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < rows; row += (int64_t)gridDim.x * WAVES) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NV], gg[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (i < nv && c < cols) {
+        const f32x4 xv = load4(x, xd, row * cols + c);
+        const f32x4 d = load4(dy, dyd, row * cols + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          gg[i][j] = d[j] * g[j];
+          s1 += gg[i][j];
+          s2 += gg[i][j] * xh[i][j];
+          ag[i][j] += d[j] * xh[i][j];
+          ab[i][j] += d[j];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / cols, c2 = wave_sum(s2) / cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (i < nv && c < cols) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (gg[i][j] - c1 - xh[i][j] * c2);
+        if (dres) {
+          const f32x4 r = load4(dres, dxd, row * cols + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += r[j];
+        }
+        store4(dx, dxd, row * cols + c, o);
+      }
+    }
+  }
+  // block partials: part[blockIdx][0][cols] = dgamma, part[blockIdx][1][cols] = dbeta
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = pass == 0 ? ag[i][j] : ab[i][j];
+      __syncthreads();
+      if (wave == 0) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < cols) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += red[w][lane * 4 + j];
+            part[((int64_t)blockIdx.x * 2 + pass) * cols + c + j] = t;
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[c] = sum_b part[b][c]   (part has `nb` rows of `width` floats)
+__global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
+                                 int nb, int cols) {
+  // width = 2*cols; thread handles one of the 2*cols columns
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * 2 * cols + c];
+  if (c < cols) out0[c] = s; else out1[c - cols] = s;
+}
+
+int ln_blocks(int64_t rows) {
+  int64_t b = cdiv(rows, WAVES);
+  return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
+}
+
+}  // namespace
+
+extern "C" int segclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                     float* rstd, int64_t rows, int64_t cols, float eps, int x_dtype, int y_dtype,
+                                     void* stream) {
+  SEGCLIP_REQUIRE(cols % 4 == 0 && cols <= MAXV * 256, "layernorm: cols=%lld must be a multiple of 4 and <= %d",
+                  (long long)cols, MAXV * 256);
+  if (rows == 0) return 0;
+  const int64_t fb = cdiv(rows, WAVES) < 4096 ? cdiv(rows, WAVES) : 4096;
+#define LNF(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)fb), dim3(WAVES * 64), 0, (hipStream_t)stream, x, \
+                                   gamma, beta, y, mean, rstd, rows, (int)cols, eps, x_dtype, y_dtype)
+  switch ((int)cdiv(cols / 4, 64)) {
+    case 1: LNF(1); break; case 2: LNF(2); break; case 3: LNF(3); break; case 4: LNF(4); break;
+    case 5: case 6: LNF(6); break; default: LNF(8); break;
+  }
+#undef LNF
+  SEGCLIP_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}
+
+extern "C" size_t segclip_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols) {
+  return (size_t)ln_blocks(rows) * 2 * cols * sizeof(float);
+}
+
+extern "C" int segclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                     const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                     void* ws, int64_t rows, int64_t cols, int dy_dtype, int x_dtype, int dx_dtype,
+                                     void* stream) {
+  SEGCLIP_REQUIRE(cols % 4 == 0 && cols <= MAXV * 256, "layernorm: cols=%lld must be a multiple of 4 and <= %d",
+                  (long long)cols, MAXV * 256);
+  SEGCLIP_REQUIRE(ws != nullptr, "layernorm_bwd: workspace required");
+  if (rows == 0) return 0;
+  const int nb = ln_blocks(rows);
+#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(nb), dim3(WAVES * 64), 0, (hipStream_t)stream, dy, x, gamma, \
+                                   mean, rstd, dres, dx, (float*)ws, rows, (int)cols, dy_dtype, x_dtype, dx_dtype)
+  switch ((int)cdiv(cols / 4, 64)) {
+    case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break;
+    case 5: case 6: LNB(6); break; default: LNB(8); break;
+  }
+#undef LNB
+  SEGCLIP_CHECK_LAUNCH("layernorm_bwd");
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)cdiv(2 * cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, dgamma, dbeta, nb, (int)cols);
+  SEGCLIP_CHECK_LAUNCH("layernorm_bwd_reduce");
+  return 0;
+}

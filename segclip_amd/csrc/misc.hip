@@ -1,0 +1,589 @@
+// HBM-bound / latency-bound helpers of the SegCLIP hot path: casts, bias-gradient column sums,
+// activations, vision/text front ends, row gathers, learnable-center hard assignment, losses and the
+// MAE masking sort.  All integer outputs (argmax, ranks) are computed in fp32/integer arithmetic only.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid1d(int64_t n, int per_thread = 1) {
+  int64_t b = cdiv(n, (int64_t)TPB * per_thread);
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+__device__ __forceinline__ float ldx(const void* p, int dtype, int64_t i) {
+  return dtype == SEGCLIP_F32 ? reinterpret_cast<const float*>(p)[i] : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+__device__ __forceinline__ void stx(void* p, int dtype, int64_t i, float v) {
+  if (dtype == SEGCLIP_F32) reinterpret_cast<float*>(p)[i] = v; else reinterpret_cast<bf16_t*>(p)[i] = f2bf(v);
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  return t;
+}
+
+// ---------------------------------------------------------------- cast / add / act
+__global__ void cast_kernel(const void* __restrict__ src, void* __restrict__ dst, int64_t n, int sd, int dd) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v;
+    if (sd == SEGCLIP_F32) v = reinterpret_cast<const f32x4*>(src)[i];
+    else {
+      const u32x2 t = reinterpret_cast<const u32x2*>(src)[i];
+      v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+      v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+    }
+    if (dd == SEGCLIP_F32) reinterpret_cast<f32x4*>(dst)[i] = v;
+    else { u32x2 t; t[0] = pack2bf(v[0], v[1]); t[1] = pack2bf(v[2], v[3]); reinterpret_cast<u32x2*>(dst)[i] = t; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    stx(dst, dd, i, ldx(src, sd, i));
+  }
+}
+__global__ void add_kernel(const void* a, const void* b, void* out, int64_t n, int dt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    stx(out, dt, i, ldx(a, dt, i) + ldx(b, dt, i));
+}
+__global__ void act_fwd_kernel(const void* x, void* y, int64_t n, int act, int dt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    stx(y, dt, i, apply_act(act, ldx(x, dt, i)));
+}
+__global__ void act_bwd_kernel(const void* dy, const void* x, void* dx, int64_t n, int act, int dt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    stx(dx, dt, i, ldx(dy, dt, i) * apply_act_grad(act, ldx(x, dt, i)));
+}
+__global__ void scale_kernel(const float* x, const float* s, float* out, int64_t n) {
+  const float sc = *s;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = x[i] * sc;
+}
+// out[0] = scale * sum(x[0..n))   (single block, deterministic)
+__global__ void reduce_sum_kernel(const float* x, float* out, int64_t n, float scale) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+constexpr int CS_ROWS = 128;  // rows per chunk
+__global__ void colsum_partial_kernel(const void* __restrict__ X, float* __restrict__ part, int64_t M, int64_t N,
+                                      int64_t ld, int dt) {
+  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (c >= N) return;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  float s0 = 0.f, s1 = 0.f;
+  const bool two = c + 1 < N;
+  for (int64_t r = r0; r < r1; ++r) {
+    s0 += ldx(X, dt, r * ld + c);
+    if (two) s1 += ldx(X, dt, r * ld + c + 1);
+  }
+  part[(int64_t)blockIdx.y * N + c] = s0;
+  if (two) part[(int64_t)blockIdx.y * N + c + 1] = s1;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t nchunk, int64_t N) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int64_t k = 0; k < nchunk; ++k) s += part[k * N + c];
+  out[c] = s;
+}
+
+// ---------------------------------------------------------------- vision front end
+// layout 0: col = c*p*p + py*p + px (conv1 weight order) ; layout 1: col = (py*p + px)*C + c (MAE patchify)
+__global__ void im2col_kernel(const float* __restrict__ img, void* __restrict__ cols, int64_t B, int C, int H, int W,
+                              int p, int layout, int od) {
+  const int gw = W / p, gh = H / p;
+  const int64_t kdim = (int64_t)C * p * p, total = B * gh * gw * kdim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / kdim;
+    const int col = (int)(i % kdim);
+    int c, py, px;
+    if (layout == 0) { c = col / (p * p); py = (col / p) % p; px = col % p; }
+    else { c = col % C; py = (col / C) / p; px = (col / C) % p; }
+    const int64_t b = row / (gh * gw);
+    const int gy = (int)((row / gw) % gh), gx = (int)(row % gw);
+    stx(cols, od, i, img[((b * C + c) * H + gy * p + py) * W + gx * p + px]);
+  }
+}
+__global__ void vis_assemble_kernel(const void* __restrict__ patches, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, float* __restrict__ x, int64_t B, int T, int D, int pd) {
+  const int64_t total = B * (T + 1) * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % (T + 1));
+    const int64_t b = i / ((int64_t)D * (T + 1));
+    const float v = t == 0 ? cls[d] : ldx(patches, pd, (b * T + (t - 1)) * D + d);
+    x[i] = v + pos[(int64_t)t * D + d];
+  }
+}
+
+// ---------------------------------------------------------------- text front end
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                 const float* __restrict__ pos, float* __restrict__ out, int64_t BL, int L, int D,
+                                 int64_t vocab) {
+  const int d4 = D / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < BL * d4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / d4;
+    const int c = (int)(i % d4);
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f32x4 e = reinterpret_cast<const f32x4*>(table + id * D)[c];
+    const f32x4 p = reinterpret_cast<const f32x4*>(pos + (row % L) * D)[c];
+    reinterpret_cast<f32x4*>(out + row * D)[c] = e + p;
+  }
+}
+__global__ void embed_bwd_table_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                       float* __restrict__ dtable, int64_t BL, int D, int64_t vocab) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < BL * D; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    atomicAdd(dtable + id * D + (i % D), dout[i]);
+  }
+}
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dout, float* __restrict__ dpos, int64_t B, int L, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over L*D
+  if (i >= (int64_t)L * D) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < B; ++b) s += dout[b * L * D + i];
+  dpos[i] = s;
+}
+
+// ---------------------------------------------------------------- row gather / scatter
+__global__ void gather_rows_kernel(const void* __restrict__ src, const int64_t* __restrict__ idx, void* __restrict__ out,
+                                   int64_t B, int Ts, int To, int D, int dt, int scatter) {
+  const int64_t total = B * To * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int64_t bj = i / D, b = bj / To;
+    int64_t t = idx[bj];
+    t = t < 0 ? 0 : (t >= Ts ? Ts - 1 : t);
+    const int64_t s = (b * Ts + t) * D + d;
+    if (!scatter) stx(out, dt, i, ldx(src, dt, s));
+    else stx(out, dt, s, ldx(out, dt, s) + ldx(src, dt, i));  // unique indices per b: no race
+  }
+}
+
+// ---------------------------------------------------------------- learnable-center assignment
+// logits (B,G,T).  One thread per (b,t).  counts accumulated with exact integer-valued float atomics.
+__global__ void assign_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel, float tau,
+                                  float* __restrict__ y_soft, float* __restrict__ soft, uint8_t* __restrict__ idx,
+                                  float* __restrict__ hard, float* __restrict__ counts, int64_t B, int G, int T) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int64_t b = i / T;
+  const int t = (int)(i % T);
+  const float* lp = logits + b * G * T + t;
+  const float* gp = gumbel ? gumbel + b * G * T + t : nullptr;
+  float m1 = -INFINITY, m2 = -INFINITY;
+  for (int g = 0; g < G; ++g) {
+    const float l = lp[(int64_t)g * T];
+    const float z = gp ? (l + gp[(int64_t)g * T]) / tau : l;
+    m1 = fmaxf(m1, z); m2 = fmaxf(m2, l);
+  }
+  float s1 = 0.f, s2 = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float l = lp[(int64_t)g * T];
+    const float z = gp ? (l + gp[(int64_t)g * T]) / tau : l;
+    s1 += expf(z - m1); s2 += expf(l - m2);
+  }
+  int best = 0; float bestv = -INFINITY;
+  for (int g = 0; g < G; ++g) {
+    const float l = lp[(int64_t)g * T];
+    const float z = gp ? (l + gp[(int64_t)g * T]) / tau : l;
+    const float y = expf(z - m1) / s1;
+    y_soft[b * G * T + (int64_t)g * T + t] = y;
+    if (soft) soft[b * G * T + (int64_t)g * T + t] = expf(l - m2) / s2;
+    if (y > bestv) { bestv = y; best = g; }  // first maximum wins (torch.max)
+  }
+  idx[i] = (uint8_t)best;
+  for (int g = 0; g < G; ++g) hard[b * G * T + (int64_t)g * T + t] = g == best ? 1.f : 0.f;
+  atomicAdd(counts + b * G + best, 1.0f);
+}
+// dlogits = softmax-bwd through y_soft/tau of the straight-through gradient dhard
+__global__ void assign_bwd_kernel(const float* __restrict__ dhard, const float* __restrict__ y_soft, float tau,
+                                  float* __restrict__ dlogits, int64_t B, int G, int T) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int64_t b = i / T;
+  const int t = (int)(i % T);
+  const int64_t base = b * G * T + t;
+  float dot = 0.f;
+  for (int g = 0; g < G; ++g) dot += dhard[base + (int64_t)g * T] * y_soft[base + (int64_t)g * T];
+  for (int g = 0; g < G; ++g) {
+    const float y = y_soft[base + (int64_t)g * T];
+    dlogits[base + (int64_t)g * T] = y * (dhard[base + (int64_t)g * T] - dot) / tau;
+  }
+}
+
+// ---------------------------------------------------------------- losses
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ norm,
+                                  int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float v = x[row * cols + c]; s += v * v; }
+  const float n = sqrtf(wave_sum(s));
+  if (lane == 0) norm[row] = n;
+  for (int c = lane; c < cols; c += 64) y[row * cols + c] = x[row * cols + c] / n;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ norm,
+                                  float* __restrict__ dx, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += dy[row * cols + c] * y[row * cols + c];
+  s = wave_sum(s);
+  const float inv = 1.f / norm[row];
+  for (int c = lane; c < cols; c += 64) dx[row * cols + c] = (dy[row * cols + c] - y[row * cols + c] * s) * inv;
+}
+// one wave per row: lse and -log softmax[label]
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, float* __restrict__ lse, float* __restrict__ loss_rows,
+                              int64_t rows, int64_t cols, int64_t label_offset) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = logits + row * cols;
+  float mx = -INFINITY;
+  for (int64_t c = lane; c < cols; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int64_t c = lane; c < cols; c += 64) s += expf(p[c] - mx);
+  s = wave_sum(s);
+  const float l = mx + logf(s);
+  if (lane == 0) { lse[row] = l; loss_rows[row] = l - p[row + label_offset]; }
+}
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse, const float* gscale_ptr,
+                              float gscale, float* __restrict__ dlogits, int64_t rows, int64_t cols, int64_t label_offset) {
+  const float gs = (gscale_ptr ? *gscale_ptr : 1.f) * gscale / (float)rows;
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cols, c = i % cols;
+    const float p = expf(logits[i] - lse[row]);
+    dlogits[i] = gs * (p - (c == row + label_offset ? 1.f : 0.f));
+  }
+}
+
+// superpixel-KL: one block per image.  hard (B,G,T) one-hot, seg (B,T) int64.  Emits loss_rows[b] (already
+// divided by coef = B*T*G and by 2) and the un-scaled gradient dhard (B,G,T) of that per-image loss.
+constexpr int KL_MAXG = 16;
+__global__ void superpixel_kl_kernel(const float* __restrict__ hard, const int64_t* __restrict__ seg,
+                                     float* __restrict__ loss_rows, float* __restrict__ dhard, int64_t B, int G, int T) {
+  extern __shared__ __attribute__((aligned(16))) char kl_smem[];
+  float* hm = reinterpret_cast<float*>(kl_smem);            // [T][G] dJ/dm per patch
+  int* lab = reinterpret_cast<int*>(hm + (size_t)T * G);    // [T] representative index of the label
+  __shared__ float red[16];
+  const int64_t b = blockIdx.x;
+  const float* h = hard + b * G * T;
+  const int64_t* sg = seg + b * T;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const int64_t me = sg[t];
+    int rep = t;
+    for (int l = 0; l < t; ++l) if (sg[l] == me) { rep = l; break; }
+    lab[t] = rep;
+  }
+  __syncthreads();
+  const float coef = (float)(B * T * G);
+  float lsum = 0.f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float a[KL_MAXG], m[KL_MAXG];
+    int n = 0;
+    for (int c = 0; c < G; ++c) m[c] = 0.f;
+    for (int l = 0; l < T; ++l)
+      if (lab[l] == lab[t]) { ++n; for (int c = 0; c < G; ++c) m[c] += h[(int64_t)c * T + l]; }
+    const float invn = 1.f / fmaxf((float)n, 1.f);
+    float ma = -INFINITY, mm = -INFINITY;
+    for (int c = 0; c < G; ++c) { a[c] = h[(int64_t)c * T + t]; m[c] *= invn; ma = fmaxf(ma, a[c]); mm = fmaxf(mm, m[c]); }
+    float sa = 0.f, sm = 0.f;
+    for (int c = 0; c < G; ++c) { sa += expf(a[c] - ma); sm += expf(m[c] - mm); }
+    const float la = ma + logf(sa), lm = mm + logf(sm);
+    float J = 0.f, sG = 0.f, sH = 0.f, Gc[KL_MAXG], Hc[KL_MAXG];
+    for (int c = 0; c < G; ++c) {
+      const float u = a[c] - la, v = m[c] - lm, q = expf(u), p = expf(v);
+      J += (p - q) * (v - u);
+      Gc[c] = -p + q - q * (v - u);
+      Hc[c] = p - q + p * (v - u);
+      sG += Gc[c]; sH += Hc[c];
+    }
+    lsum += J;
+    for (int c = 0; c < G; ++c) {
+      const float u = a[c] - la, v = m[c] - lm;
+      // direct path through log_softmax(h)/softmax(h)
+      dhard[b * G * T + (int64_t)c * T + t] = (Gc[c] - expf(u) * sG) * (0.5f / coef);
+      hm[(size_t)t * G + c] = (Hc[c] - expf(v) * sH) * invn * (0.5f / coef);
+    }
+  }
+  __syncthreads();
+  // path through the superpixel mean: dh[l,:] += sum_{g in S(l)} dJ/dm[g,:] / n_g
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float acc[KL_MAXG];
+    for (int c = 0; c < G; ++c) acc[c] = 0.f;
+    for (int g = 0; g < T; ++g)
+      if (lab[g] == lab[t]) for (int c = 0; c < G; ++c) acc[c] += hm[(size_t)g * G + c];
+    for (int c = 0; c < G; ++c) dhard[b * G * T + (int64_t)c * T + t] += acc[c];
+  }
+  lsum = block_sum(lsum, red);
+  if (threadIdx.x == 0) loss_rows[b] = lsum * 0.5f / coef;
+}
+
+// MAE masked MSE: per (b,t) row: mask * mean_d (pred - target)^2 ; one wave per row
+__global__ void masked_mse_fwd_kernel(const void* __restrict__ pred, const float* __restrict__ target,
+                                      const float* __restrict__ mask, float* __restrict__ loss_rows, int64_t B, int T,
+                                      int Dp, int pd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int64_t b = row / T, t = row % T;
+  const float mk = mask[b * (T + 1) + 1 + t];
+  float s = 0.f;
+  if (mk != 0.f)
+    for (int d = lane; d < Dp; d += 64) {
+      const float e = ldx(pred, pd, (b * (T + 1) + 1 + t) * Dp + d) - target[row * Dp + d];
+      s += e * e;
+    }
+  s = wave_sum(s);
+  if (lane == 0) loss_rows[row] = mk * s / Dp;
+}
+// dpred (B,1+T,Dp): row 0 zero; gs = gscale * (*gptr) / sum(mask)
+__global__ void masked_mse_bwd_kernel(const void* __restrict__ pred, const float* __restrict__ target,
+                                      const float* __restrict__ mask, const float* gptr, const float* msum, float gscale,
+                                      void* __restrict__ dpred, int64_t B, int T, int Dp, int pd) {
+  const float gs = (gptr ? *gptr : 1.f) * gscale / (*msum) * 2.f / Dp;
+  const int64_t total = B * (T + 1) * Dp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % Dp);
+    const int64_t bt = i / Dp, b = bt / (T + 1), t1 = bt % (T + 1);
+    float v = 0.f;
+    if (t1 > 0) {
+      const float mk = mask[bt];
+      if (mk != 0.f) v = gs * mk * (ldx(pred, pd, i) - target[(b * T + t1 - 1) * Dp + d]);
+    }
+    stx(dpred, pd, i, v);
+  }
+}
+
+// MAE masking: stable rank sort per row (L <= 4096), one block per row
+__global__ void mask_sort_kernel(const float* __restrict__ noise, int64_t* __restrict__ ids_shuffle,
+                                 int64_t* __restrict__ ids_restore, float* __restrict__ mask, int L, int len_keep) {
+  extern __shared__ __attribute__((aligned(16))) char ms_smem[];
+  float* nz = reinterpret_cast<float*>(ms_smem);
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) nz[i] = i == 0 ? -1.0f : noise[b * L + i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    const float v = nz[i];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) { const float w = nz[j]; rank += (w < v) || (w == v && j < i); }
+    ids_restore[b * L + i] = rank;
+    ids_shuffle[b * L + rank] = i;
+    mask[b * L + i] = rank >= len_keep ? 1.f : 0.f;
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int segclip_cast(const void* src, void* dst, int64_t n, int sd, int dd, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid1d(n, 4)), dim3(TPB), 0, ST, src, dst, n, sd, dd);
+  SEGCLIP_CHECK_LAUNCH("cast");
+  return 0;
+}
+extern "C" int segclip_add(const void* a, const void* b, void* out, int64_t n, int dt, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, a, b, out, n, dt);
+  SEGCLIP_CHECK_LAUNCH("add");
+  return 0;
+}
+extern "C" int segclip_act_fwd(const void* x, void* y, int64_t n, int act, int dt, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, x, y, n, act, dt);
+  SEGCLIP_CHECK_LAUNCH("act_fwd");
+  return 0;
+}
+extern "C" int segclip_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dt, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, dy, x, dx, n, act, dt);
+  SEGCLIP_CHECK_LAUNCH("act_bwd");
+  return 0;
+}
+extern "C" int segclip_scale(const float* x, const float* s, float* out, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, x, s, out, n);
+  SEGCLIP_CHECK_LAUNCH("scale");
+  return 0;
+}
+extern "C" int segclip_reduce_sum(const float* x, float* out, int64_t n, float scale, void* stream) {
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, ST, x, out, n, scale);
+  SEGCLIP_CHECK_LAUNCH("reduce_sum");
+  return 0;
+}
+extern "C" size_t segclip_colsum_ws_bytes(int64_t M, int64_t N) { return (size_t)cdiv(M, CS_ROWS) * N * sizeof(float); }
+extern "C" int segclip_colsum(const void* X, float* out, void* ws, int64_t M, int64_t N, int64_t ld, int dt, void* stream) {
+  SEGCLIP_REQUIRE(ws != nullptr, "colsum: workspace required");
+  if (N == 0) return 0;
+  const int64_t nchunk = cdiv(M, CS_ROWS);
+  if (nchunk > 0) {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cdiv(N, 2), 128), (unsigned)nchunk), dim3(128), 0, ST, X,
+                       (float*)ws, M, N, ld, dt);
+    SEGCLIP_CHECK_LAUNCH("colsum_partial");
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, ST, (const float*)ws, out, nchunk, N);
+  SEGCLIP_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+extern "C" int segclip_im2col(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                              int layout, int od, void* stream) {
+  SEGCLIP_REQUIRE(H % p == 0 && W % p == 0, "im2col: %lldx%lld not divisible by patch %lld", (long long)H, (long long)W,
+                  (long long)p);
+  const int64_t total = B * C * H * W;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid1d(total)), dim3(TPB), 0, ST, image, cols, B, (int)C, (int)H, (int)W, (int)p,
+                     layout, od);
+  SEGCLIP_CHECK_LAUNCH("im2col");
+  return 0;
+}
+extern "C" int segclip_vis_assemble(const void* patches, const float* cls, const float* pos, float* x, int64_t B, int64_t T,
+                                    int64_t D, int pd, void* stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(vis_assemble_kernel, dim3(grid1d(B * (T + 1) * D)), dim3(TPB), 0, ST, patches, cls, pos, x, B, (int)T,
+                     (int)D, pd);
+  SEGCLIP_CHECK_LAUNCH("vis_assemble");
+  return 0;
+}
+extern "C" int segclip_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* out, int64_t B, int64_t L,
+                                 int64_t D, int64_t vocab, void* stream) {
+  SEGCLIP_REQUIRE(D % 4 == 0, "embed: D=%lld must be a multiple of 4", (long long)D);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid1d(B * L * D / 4)), dim3(TPB), 0, ST, ids, table, pos, out, B * L, (int)L,
+                     (int)D, vocab);
+  SEGCLIP_CHECK_LAUNCH("embed_fwd");
+  return 0;
+}
+extern "C" int segclip_embed_bwd(const int64_t* ids, const float* dout, float* dtable, float* dpos, int64_t B, int64_t L,
+                                 int64_t D, int64_t vocab, void* stream) {
+  if (B == 0) return 0;
+  if (dtable) {
+    hipLaunchKernelGGL(embed_bwd_table_kernel, dim3(grid1d(B * L * D)), dim3(TPB), 0, ST, ids, dout, dtable, B * L, (int)D,
+                       vocab);
+    SEGCLIP_CHECK_LAUNCH("embed_bwd_table");
+  }
+  if (dpos) {
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)cdiv(L * D, TPB)), dim3(TPB), 0, ST, dout, dpos, B, (int)L, (int)D);
+    SEGCLIP_CHECK_LAUNCH("embed_bwd_pos");
+  }
+  return 0;
+}
+extern "C" int segclip_gather_rows(const void* src, const int64_t* idx, void* out, int64_t B, int64_t Ts, int64_t To,
+                                   int64_t D, int dt, void* stream) {
+  if (B * To * D == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(B * To * D)), dim3(TPB), 0, ST, src, idx, out, B, (int)Ts, (int)To,
+                     (int)D, dt, 0);
+  SEGCLIP_CHECK_LAUNCH("gather_rows");
+  return 0;
+}
+extern "C" int segclip_scatter_rows(const void* dout, const int64_t* idx, void* dsrc, int64_t B, int64_t Ts, int64_t To,
+                                    int64_t D, int dt, void* stream) {
+  if (B * To * D == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(B * To * D)), dim3(TPB), 0, ST, dout, idx, dsrc, B, (int)Ts, (int)To,
+                     (int)D, dt, 1);
+  SEGCLIP_CHECK_LAUNCH("scatter_rows");
+  return 0;
+}
+extern "C" int segclip_assign_fwd(const float* logits, const float* gumbel, float tau, float* y_soft, float* soft,
+                                  uint8_t* idx, float* hard, float* counts, int64_t B, int64_t G, int64_t T, void* stream) {
+  SEGCLIP_REQUIRE(G <= 255, "assign: G=%lld too large", (long long)G);
+  if (B == 0) return 0;
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * G * sizeof(float), ST);
+  SEGCLIP_REQUIRE(e == hipSuccess, "assign: memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(assign_fwd_kernel, dim3((unsigned)cdiv(B * T, TPB)), dim3(TPB), 0, ST, logits, gumbel, tau, y_soft,
+                     soft, idx, hard, counts, B, (int)G, (int)T);
+  SEGCLIP_CHECK_LAUNCH("assign_fwd");
+  return 0;
+}
+extern "C" int segclip_assign_bwd(const float* dhard, const float* y_soft, float tau, float* dlogits, int64_t B, int64_t G,
+                                  int64_t T, void* stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(assign_bwd_kernel, dim3((unsigned)cdiv(B * T, TPB)), dim3(TPB), 0, ST, dhard, y_soft, tau, dlogits, B,
+                     (int)G, (int)T);
+  SEGCLIP_CHECK_LAUNCH("assign_bwd");
+  return 0;
+}
+extern "C" int segclip_l2norm_fwd(const float* x, float* y, float* norm, int64_t rows, int64_t cols, void* stream) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, ST, x, y, norm, rows, (int)cols);
+  SEGCLIP_CHECK_LAUNCH("l2norm_fwd");
+  return 0;
+}
+extern "C" int segclip_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int64_t rows, int64_t cols,
+                                  void* stream) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, ST, dy, y, norm, dx, rows, (int)cols);
+  SEGCLIP_CHECK_LAUNCH("l2norm_bwd");
+  return 0;
+}
+extern "C" int segclip_ce_fwd(const float* logits, float* lse, float* loss_rows, int64_t rows, int64_t cols,
+                              int64_t label_offset, void* stream) {
+  SEGCLIP_REQUIRE(rows + label_offset <= cols && label_offset >= 0, "ce: labels [%lld,%lld) outside %lld columns",
+                  (long long)label_offset, (long long)(rows + label_offset), (long long)cols);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, ST, logits, lse, loss_rows, rows, cols,
+                     label_offset);
+  SEGCLIP_CHECK_LAUNCH("ce_fwd");
+  return 0;
+}
+extern "C" int segclip_ce_bwd(const float* logits, const float* lse, const float* gscale_ptr, float gscale, float* dlogits,
+                              int64_t rows, int64_t cols, int64_t label_offset, void* stream) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid1d(rows * cols)), dim3(TPB), 0, ST, logits, lse, gscale_ptr, gscale, dlogits,
+                     rows, cols, label_offset);
+  SEGCLIP_CHECK_LAUNCH("ce_bwd");
+  return 0;
+}
+extern "C" int segclip_superpixel_kl(const float* hard, const int64_t* seg, float* loss_rows, float* dhard, int64_t B,
+                                     int64_t G, int64_t T, void* stream) {
+  SEGCLIP_REQUIRE(G <= KL_MAXG, "superpixel_kl: G=%lld > %d", (long long)G, KL_MAXG);
+  const size_t sm = (size_t)T * G * sizeof(float) + (size_t)T * sizeof(int);
+  SEGCLIP_REQUIRE(sm <= 60000, "superpixel_kl: T=%lld too large", (long long)T);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(superpixel_kl_kernel, dim3((unsigned)B), dim3(256), sm, ST, hard, seg, loss_rows, dhard, B, (int)G, (int)T);
+  SEGCLIP_CHECK_LAUNCH("superpixel_kl");
+  return 0;
+}
+extern "C" int segclip_masked_mse_fwd(const void* pred, const float* target, const float* mask, float* loss_rows, int64_t B,
+                                      int64_t T, int64_t Dp, int pd, void* stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(masked_mse_fwd_kernel, dim3((unsigned)cdiv(B * T, 4)), dim3(256), 0, ST, pred, target, mask, loss_rows, B,
+                     (int)T, (int)Dp, pd);
+  SEGCLIP_CHECK_LAUNCH("masked_mse_fwd");
+  return 0;
+}
+extern "C" int segclip_masked_mse_bwd(const void* pred, const float* target, const float* mask, const float* gscale_ptr,
+                                      const float* mask_sum, float gscale, void* dpred, int64_t B, int64_t T, int64_t Dp,
+                                      int pd, void* stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3(grid1d(B * (T + 1) * Dp)), dim3(TPB), 0, ST, pred, target, mask, gscale_ptr,
+                     mask_sum, gscale, dpred, B, (int)T, (int)Dp, pd);
+  SEGCLIP_CHECK_LAUNCH("masked_mse_bwd");
+  return 0;
+}
+extern "C" int segclip_mask_sort(const float* noise, int64_t* ids_shuffle, int64_t* ids_restore, float* mask, int64_t B,
+                                 int64_t L, int64_t len_keep, void* stream) {
+  SEGCLIP_REQUIRE(L <= 4096, "mask_sort: L=%lld > 4096", (long long)L);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(mask_sort_kernel, dim3((unsigned)B), dim3(256), (size_t)L * sizeof(float), ST, noise, ids_shuffle,
+                     ids_restore, mask, (int)L, (int)len_keep);
+  SEGCLIP_CHECK_LAUNCH("mask_sort");
+  return 0;
+}

@@ -1,0 +1,123 @@
+"""Mirror of modules/module_mae.py (vision path): MAE decoder, patchify, 2-D sin-cos table."""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import config, ops
+
+
+def patchify(imgs, patch_size):
+    """modules/module_mae.py:18-29."""
+    return ops.patchify_target(imgs.float(), patch_size)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False):
+    """modules/module_mae.py:63-108 (float64 numpy, 'w goes first')."""
+    grid_h = np.arange(grid_size, dtype=np.float32)
+    grid_w = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, grid_size, grid_size])
+
+    def one(d, pos):
+        omega = np.arange(d // 2, dtype=np.float64) / (d / 2.)
+        omega = 1. / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    emb = np.concatenate([one(embed_dim // 2, grid[0]), one(embed_dim // 2, grid[1])], axis=1)
+    if cls_token:
+        emb = np.concatenate([np.zeros([1, embed_dim]), emb], axis=0)
+    return emb
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Block(nn.Module):
+    """timm-style block, modules/module_mae.py:185-201 (qkv bias, erf GELU, LN eps from norm_layer)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        qb = self.attn.qkv.bias
+        if qb is None:
+            qb = torch.zeros(self.attn.qkv.weight.shape[0], device=x.device, dtype=torch.float32)
+        return ops.ResBlockFn.apply(x.float(), self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, qb,
+                                    self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight, self.norm2.bias,
+                                    self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
+                                    self.attn.num_heads, False, ops.ACT_GELU_ERF, self.norm1.eps, config.compute_dtype)
+
+
+class MAEDecoder(nn.Module):
+    """modules/module_mae.py:235-330 (choice_seq=False path)."""
+
+    def __init__(self, embed_dim, decoder_embed_dim, image_resolution, patch_size, decoder_depth=8,
+                 decoder_num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm, in_chans=3, choice_seq=False,
+                 pred_len=None, seq_len=None):
+        super().__init__()
+        if choice_seq:
+            raise NotImplementedError("text-MAE decoder (forward_seq) is out of scope")
+        self.pred_len = patch_size ** 2 * in_chans
+        self.patch_size = patch_size
+        self.num_patches = (image_resolution // patch_size) ** 2
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, decoder_embed_dim),
+                                              requires_grad=False)
+        self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True,
+                                                   norm_layer=norm_layer) for _ in range(decoder_depth)])
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.decoder_pred = nn.Linear(decoder_embed_dim, self.pred_len, bias=True)
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        pe = get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], int(self.num_patches ** .5), cls_token=True)
+        self.decoder_pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
+        torch.nn.init.normal_(self.mask_token, std=.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward_vis(self, image, vis_hidden, vis_mae_mask, vis_mae_ids_restore, loss_allpatch=False):
+        if loss_allpatch:
+            raise NotImplementedError("loss_allpatch=True is never used by the reference forward")
+        ad = config.compute_dtype
+        B, Kk, _ = vis_hidden.shape
+        Lq = vis_mae_ids_restore.shape[1]
+        x = ops.linear(vis_hidden.float(), self.decoder_embed.weight, self.decoder_embed.bias, out_dtype=torch.float32,
+                       act_dtype=ad)
+        Dd = x.shape[-1]
+        mask_tokens = self.mask_token.float().expand(B, Lq - Kk, Dd)
+        x_ = torch.cat([x, mask_tokens], dim=1)
+        x = ops.GatherRowsFn.apply(x_, vis_mae_ids_restore)
+        x = x + self.decoder_pos_embed.float()
+        for blk in self.decoder_blocks:
+            x = blk(x)
+        x = ops.layer_norm(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps, ad)
+        pred = ops.linear(x, self.decoder_pred.weight, self.decoder_pred.bias, out_dtype=torch.float32, act_dtype=ad)
+        target = patchify(image, self.patch_size)
+        return ops.MaskedMSEFn.apply(pred, target, vis_mae_mask.float().contiguous())

@@ -1,0 +1,747 @@
+"""Host-side operator layer: raw launches of the C-ABI kernels (p_* functions, no autograd) and the
+torch.autograd.Function wrappers the module mirror (segclip_amd/modules) is built from.
+
+torch is used for device memory (caching allocator), streams, autograd bookkeeping and
+torch.distributed - every FLOP-carrying op of the hot path is a call into libsegclip_hip.so.
+There is no CPU fallback: tensors must live on the GPU.
+
+Activation dtype == compute mode: torch.float32 -> exact-f32 MFMA path, torch.bfloat16 -> bf16 MFMA
+path (fp32 residual stream, fp32 parameters / parameter gradients in both modes).
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from . import _lib as L
+
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = L.ACT_NONE, L.ACT_QUICK_GELU, L.ACT_GELU_ERF
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _off(t, off):
+    if t is None:
+        return None
+    L.require_cuda(t)
+    return C.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches
+# ------------------------------------------------------------------------------------------------
+def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=None, residual=None, ldr=0,
+           r_off=0, aux=None, ldaux=0, act=ACT_NONE, mul_dact=False, alpha=1.0, nb1=1, nb2=1, bsA=(0, 0),
+           bsB=(0, 0), bsC=(0, 0), bsR=None):
+    """C(m,n) = epi(alpha * sum_k A(m,k) B(n,k)); sa = (sam, sak), sb = (sbn, sbk) element strides."""
+    lib = L.load()
+    L.require_cuda(A, B, Cc)
+    d = L.GemmDesc()
+    d.A, d.B, d.C = _off(A, a_off), _off(B, b_off), _off(Cc, c_off)
+    d.bias = L.ptr(bias)
+    d.residual = _off(residual, r_off)
+    d.aux = _off(aux, c_off) if aux is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.sam, d.sak = sa
+    d.sbn, d.sbk = sb
+    d.ldc, d.ldr, d.ldaux = ldc, ldr, ldaux
+    d.nb1, d.nb2 = nb1, nb2
+    d.bsA1, d.bsA2 = bsA
+    d.bsB1, d.bsB2 = bsB
+    d.bsC1, d.bsC2 = bsC
+    d.bsR1, d.bsR2 = bsC if bsR is None else bsR
+    d.a_dtype, d.b_dtype, d.c_dtype = L.dt(A), L.dt(B), L.dt(Cc)
+    d.r_dtype = L.dt(residual) if residual is not None else L.F32
+    if aux is not None and aux.dtype != Cc.dtype:
+        raise TypeError("gemm: aux dtype must equal output dtype")
+    d.act, d.mul_dact, d.alpha = act, int(mul_dact), float(alpha)
+    ws = None
+    nbytes = lib.segclip_gemm_ws_bytes(C.byref(d))
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+        d.ws, d.ws_bytes = L.ptr(ws), nbytes
+    L.check(lib.segclip_gemm(C.byref(d), L.stream()), "gemm")
+    return Cc
+
+
+def _ld(x):
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError(f"expected a 2-D row-major view, got shape {tuple(x.shape)} strides {x.stride()}")
+    return x.stride(0)
+
+
+def p_cast(t, dtype):
+    if t.dtype == dtype:
+        return t
+    t = t.contiguous()
+    out = torch.empty_like(t, dtype=dtype)
+    L.check(L.load().segclip_cast(L.ptr(t), L.ptr(out), t.numel(), L.dt(t), L.dt(out), L.stream()), "cast")
+    return out
+
+
+def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_dtype=None, w_kn=False):
+    """y = act(x w^T + bias) + residual.  x (M,K) view; w (N,K) [or (K,N) when w_kn]; same dtype family."""
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    out_dtype = out_dtype or x.dtype
+    y = _empty((M, N), out_dtype, x)
+    aux = _empty((M, N), out_dtype, x) if (want_aux and act != ACT_NONE) else None
+    sb = (1, w.stride(0)) if w_kn else (w.stride(0), 1)
+    p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, N, bias=bias, residual=residual,
+           ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=N, act=act)
+    return y, aux
+
+
+def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False):
+    """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)."""
+    M, N = dy.shape
+    K = w.shape[0] if w_kn else w.shape[1]
+    dx = _empty((M, K), out_dtype, dy)
+    sb = (w.stride(0), 1) if w_kn else (1, w.stride(0))
+    if aux is not None and aux.dtype != out_dtype:
+        raise TypeError("dgrad: aux dtype must equal output dtype")
+    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None)
+    return dx
+
+
+def p_wgrad(dy, x, w_kn=False):
+    """dw = dy^T x (N,K) fp32  [or x^T dy (K,N) when w_kn];  dy (M,N), x (M,K)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if w_kn:
+        if x.dtype == torch.float32 and dy.dtype != torch.float32:
+            x = p_cast(x, dy.dtype)
+        dw = _empty((K, N), torch.float32, dy)
+        if dy.dtype == torch.float32 and x.dtype != torch.float32:
+            dy = p_cast(dy, x.dtype)
+        p_gemm(x, dy, dw, K, N, M, (1, _ld(x)), (1, _ld(dy)), N)
+        return dw
+    if x.dtype == torch.float32 and dy.dtype != torch.float32:
+        x = p_cast(x, dy.dtype)  # only the A operand may be fp32 on the bf16 path
+    dw = _empty((N, K), torch.float32, dy)
+    p_gemm(dy, x, dw, N, K, M, (1, _ld(dy)), (1, _ld(x)), K)
+    return dw
+
+
+def p_colsum(x):
+    M, N = x.shape
+    lib = L.load()
+    out = _empty((N,), torch.float32, x)
+    ws = torch.empty(max(lib.segclip_colsum_ws_bytes(M, N), 4), dtype=torch.uint8, device=x.device)
+    L.check(lib.segclip_colsum(L.ptr(x), L.ptr(out), L.ptr(ws), M, N, _ld(x), L.dt(x), L.stream()), "colsum")
+    return out
+
+
+def p_ln_fwd(x, w, b, eps, out_dtype):
+    x = x.contiguous()
+    rows, cols = x.shape
+    y = _empty((rows, cols), out_dtype, x)
+    mean = _empty((rows,), torch.float32, x)
+    rstd = _empty((rows,), torch.float32, x)
+    L.check(L.load().segclip_layernorm_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows,
+                                           cols, eps, L.dt(x), L.dt(y), L.stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None):
+    lib = L.load()
+    dy = dy.contiguous()
+    rows, cols = x.shape
+    dx_dtype = dx_dtype or x.dtype
+    dx = _empty((rows, cols), dx_dtype, x)
+    dw = _empty((cols,), torch.float32, x)
+    db = _empty((cols,), torch.float32, x)
+    if dres is not None:
+        dres = dres.contiguous()
+        if dres.dtype != dx_dtype:
+            raise TypeError("layernorm_bwd: dres dtype must equal dx dtype")
+    ws = torch.empty(max(lib.segclip_layernorm_bwd_ws_bytes(rows, cols), 4), dtype=torch.uint8, device=x.device)
+    L.check(lib.segclip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
+                                      L.ptr(dw), L.ptr(db), L.ptr(ws), rows, cols, L.dt(dy), L.dt(x), L.dt(dx),
+                                      L.stream()), "layernorm_bwd")
+    return dx, dw, db
+
+
+def _attn_desc(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, scale, causal, q_off=0, k_off=0, v_off=0):
+    d = L.AttnDesc()
+    d.Q, d.K, d.V, d.O = _off(q, q_off), _off(k, k_off), _off(v, v_off), L.ptr(o)
+    d.B, d.H, d.Tq, d.Tk, d.hd = B, H, Tq, Tk, hd
+    d.q_sb, d.q_st = qs
+    d.k_sb, d.k_st = ks
+    d.v_sb, d.v_st = vs
+    d.o_sb, d.o_st = os_
+    d.scale, d.causal, d.dtype = float(scale), int(causal), L.dt(q)
+    return d
+
+
+def p_attn_fwd(d, like):
+    lib = L.load()
+    stats = torch.empty(max(lib.segclip_attn_stats_bytes(C.byref(d)) // 4, 1), dtype=torch.float32, device=like.device)
+    d.stats = L.ptr(stats)
+    L.check(lib.segclip_attn_fwd(C.byref(d), L.stream()), "attn_fwd")
+    return stats
+
+
+def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0, dv_off=0):
+    lib = L.load()
+    d.stats = L.ptr(stats)
+    d.dO, d.dQ, d.dK, d.dV = L.ptr(do), _off(dq, dq_off), _off(dk, dk_off), _off(dv, dv_off)
+    d.dq_sb, d.dq_st = dqs
+    d.dk_sb, d.dk_st = dks
+    d.dv_sb, d.dv_st = dvs
+    d.do_sb, d.do_st = dos
+    nbytes = lib.segclip_attn_bwd_ws_bytes(C.byref(d))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=do.device)
+    d.ws = L.ptr(ws)
+    L.check(lib.segclip_attn_bwd(C.byref(d), L.stream()), "attn_bwd")
+
+
+def wcast(w, act_dtype):
+    """Parameter (fp32 master) in the compute dtype of the current mode."""
+    return p_cast(w.detach(), act_dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    """modules/module_clip_util.py:126-132 / nn.LayerNorm.  x (rows, cols)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, out_dtype):
+        x = x.contiguous()
+        y, mean, rstd = p_ln_fwd(x, w, b, eps, out_dtype)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = p_ln_bwd(dy, x, w, mean, rstd, None, x.dtype)
+        return dx, dw, db, None, None
+
+
+def layer_norm(x, w, b, eps=1e-5, out_dtype=None):
+    shp = x.shape
+    y = LayerNormFn.apply(x.reshape(-1, shp[-1]), w, b, eps, out_dtype or x.dtype)
+    return y.view(shp)
+
+
+class LinearFn(Function):
+    """y = act(x w^T + b) + residual (nn.Linear / `@ proj`).  x (M,K); w (N,K) or (K,N) if w_kn."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, act, out_dtype, act_dtype, w_kn):
+        if x.dtype != act_dtype:
+            x = p_cast(x, act_dtype)
+        wc = wcast(w, act_dtype)
+        y, aux = p_linear(x, wc, b, act, residual, want_aux=True, out_dtype=out_dtype, w_kn=w_kn)
+        ctx.save_for_backward(x, wc, aux)
+        ctx.act, ctx.w_kn, ctx.has_b, ctx.has_r = act, w_kn, b is not None, residual is not None
+        ctx.act_dtype = act_dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc, aux = ctx.saved_tensors
+        dy = dy.contiguous()
+        du = dy
+        if ctx.act != ACT_NONE:
+            du = torch.empty_like(dy)
+            L.check(L.load().segclip_act_bwd(L.ptr(dy), L.ptr(aux), L.ptr(du), dy.numel(), ctx.act, L.dt(dy),
+                                             L.stream()), "act_bwd")
+        dx = p_dgrad(du, wc, x.dtype, w_kn=ctx.w_kn) if ctx.needs_input_grad[0] else None
+        dw = p_wgrad(du, x, w_kn=ctx.w_kn) if ctx.needs_input_grad[1] else None
+        db = p_colsum(du) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dres = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None, None, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, residual=None, out_dtype=None, act_dtype=None, w_kn=False):
+    shp = x.shape
+    act_dtype = act_dtype or x.dtype
+    out_dtype = out_dtype or act_dtype
+    N = w.shape[1] if w_kn else w.shape[0]
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), w, b, r2, act, out_dtype, act_dtype, w_kn)
+    return y.view(*shp[:-1], N)
+
+
+class BmmFn(Function):
+    """C[b] = A[b] @ B[b]  (transB: A[b] @ B[b]^T).  3-D operands of one dtype with arbitrary (b, row)
+    strides and unit stride on one of the two inner axes; used for the small contractions of the center
+    stage (modules/module_seg_vit.py:304,309,342) and the contrastive logits (modules/modeling.py:356-357)."""
+
+    @staticmethod
+    def forward(ctx, A, B, transB, out_dtype):
+        if A.dtype != B.dtype:
+            raise TypeError(f"bmm: operand dtypes differ ({A.dtype} vs {B.dtype})")
+        nb, M, K = A.shape
+        N = B.shape[1] if transB else B.shape[2]
+        Cc = _empty((nb, M, N), out_dtype, A)
+        sb = (B.stride(1), B.stride(2)) if transB else (B.stride(2), B.stride(1))
+        p_gemm(A, B, Cc, M, N, K, (A.stride(1), A.stride(2)), sb, N, nb1=nb, bsA=(A.stride(0), 0),
+               bsB=(B.stride(0), 0), bsC=(M * N, 0))
+        ctx.save_for_backward(A, B)
+        ctx.transB = transB
+        return Cc
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        nb, M, K = A.shape
+        dC = p_cast(dC.contiguous(), A.dtype)
+        N = dC.shape[2]
+        dA = dB = None
+        sn, sk = (B.stride(1), B.stride(2)) if ctx.transB else (B.stride(2), B.stride(1))  # Bop(n,k)
+        if ctx.needs_input_grad[0]:
+            # dA(m,k) = sum_n dC(m,n) Bop(n,k): contraction over n
+            dA = _empty((nb, M, K), A.dtype, A)
+            p_gemm(dC, B, dA, M, K, N, (N, 1), (sk, sn), K, nb1=nb, bsA=(M * N, 0), bsB=(B.stride(0), 0),
+                   bsC=(M * K, 0))
+        if ctx.needs_input_grad[1]:
+            if ctx.transB:
+                # dB(n,k) = sum_m dC(m,n) A(m,k)
+                dB = _empty((nb, N, K), B.dtype, B)
+                p_gemm(dC, A, dB, N, K, M, (1, N), (A.stride(2), A.stride(1)), K, nb1=nb, bsA=(M * N, 0),
+                       bsB=(A.stride(0), 0), bsC=(N * K, 0))
+            else:
+                # dB(k,n) = sum_m A(m,k) dC(m,n)
+                dB = _empty((nb, K, N), B.dtype, B)
+                p_gemm(A, dC, dB, K, N, M, (A.stride(2), A.stride(1)), (1, N), N, nb1=nb, bsA=(A.stride(0), 0),
+                       bsB=(M * N, 0), bsC=(K * N, 0))
+        return dA, dB, None, None
+
+
+def bmm(A, B, transB=False, out_dtype=None):
+    return BmmFn.apply(A, B, transB, out_dtype or A.dtype)
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.load().segclip_act_fwd(L.ptr(x), L.ptr(y), x.numel(), act, L.dt(x), L.stream()), "act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().segclip_act_bwd(L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), ctx.act, L.dt(x), L.stream()),
+                "act_bwd")
+        return dx, None
+
+
+class ResBlockFn(Function):
+    """One pre-LN residual attention block as ONE autograd node (modules/module_seg_vit.py:162-196,
+    modules/module_clip_ttransformer.py:20-52, modules/module_mae.py:185-201):
+        x += out_proj(MHA(LN1 x));  x += c_proj(act(c_fc(LN2 x)))
+    x (B,T,D) fp32 residual stream.  Backward is hand-scheduled: residual-gradient adds are fused into
+    the LayerNorm backward, act' into the c_proj dgrad epilogue, and no gradient is re-read."""
+
+    @staticmethod
+    def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr, n_head, causal, act, eps,
+                act_dtype):
+        B, T, D = x.shape
+        M = B * T
+        x2 = x.contiguous().view(M, D)
+        hd = D // n_head
+        y1, mean1, rstd1 = p_ln_fwd(x2, ln1w, ln1b, eps, act_dtype)
+        wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (wqkv, wo, wfc, wpr))
+        qkv, _ = p_linear(y1, wqkv_c, bqkv)
+        o = _empty((M, D), act_dtype, x)
+        ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, (T * 3 * D, 3 * D), (T * 3 * D, 3 * D),
+                        (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D)
+        stats = p_attn_fwd(ad, x)
+        x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
+        y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
+        h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True)
+        xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
+        ctx.save_for_backward(x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2,
+                              wfc_c, u, h, wpr_c)
+        ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
+        return xo.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h,
+         wpr_c) = ctx.saved_tensors
+        B, T, D, n_head, causal, act, act_dtype = ctx.cfg
+        M = B * T
+        hd = D // n_head
+        g = g.contiguous().view(M, D)
+        need = ctx.needs_input_grad
+        # ---- MLP
+        du = p_dgrad(g, wpr_c, act_dtype, aux=u, act=act)          # (dy c_proj) * act'(u)
+        dwpr = p_wgrad(g, h) if need[11] else None
+        dbpr = p_colsum(g) if need[12] else None
+        dy2 = p_dgrad(du, wfc_c, act_dtype)
+        dwfc = p_wgrad(du, y2) if need[9] else None
+        dbfc = p_colsum(du) if need[10] else None
+        dx1, dln2w, dln2b = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32)
+        # ---- attention
+        do = p_dgrad(dx1, wo_c, act_dtype)
+        dwo = p_wgrad(dx1, o) if need[5] else None
+        dbo = p_colsum(dx1) if need[6] else None
+        dqkv = _empty((M, 3 * D), act_dtype, g)
+        s3 = (T * 3 * D, 3 * D)
+        ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
+                        0, D, 2 * D)
+        p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D)
+        dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
+        dwqkv = p_wgrad(dqkv, y1) if need[3] else None
+        dbqkv = p_colsum(dqkv) if need[4] else None
+        dx, dln1w, dln1b = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32)
+        return (dx.view(B, T, D), dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr, None,
+                None, None, None, None)
+
+
+class CrossAttnFn(Function):
+    """Attention core of CrossAttentionBlock (modules/module_seg_vit.py:215): queries (B*G, D) against
+    the projected [centers; patches] buffer kv (B*S, 2D) = [K | V].
+    mode "t18": the torch-1.8 key reshape reinterprets the (B,S,D) buffer as (S,B,D): sample b attends to
+    flat tokens {r*B + b} (SURVEY.md finding 0.4).  mode "intended": its own S tokens."""
+
+    @staticmethod
+    def forward(ctx, qp, kv, B, G, S, n_head, mode):
+        D = qp.shape[1]
+        hd = D // n_head
+        o = torch.empty_like(qp)
+        ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
+        ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd),
+                        False, 0, 0, D)
+        stats = p_attn_fwd(ad, qp)
+        ctx.save_for_backward(qp, kv, o, stats)
+        ctx.cfg = (B, G, S, n_head, mode)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qp, kv, o, stats = ctx.saved_tensors
+        B, G, S, n_head, mode = ctx.cfg
+        D = qp.shape[1]
+        hd = D // n_head
+        do = do.contiguous()
+        ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
+        ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd),
+                        False, 0, 0, D)
+        dq = torch.empty_like(qp)
+        dkv = torch.empty_like(kv)
+        p_attn_bwd(ad, stats, do, dq, dkv, dkv, (G * D, D), ks, ks, (G * D, D), 0, 0, D)
+        return dq, dkv, None, None, None, None, None
+
+
+class PatchEmbedFn(Function):
+    """conv1 (16x16/16, no bias) as im2col + GEMM with the positional table fused as the epilogue
+    residual (modules/module_clip_vtransformer.py:56-64).  The CLS row the reference prepends is
+    discarded by SegViT before any use (modules/module_seg_vit.py:419), so it is never materialised;
+    class_embedding therefore receives an all-zero gradient, exactly as in the reference."""
+
+    @staticmethod
+    def forward(ctx, image, conv_w, cls, pos, patch, act_dtype):
+        lib = L.load()
+        B, Cc, H, W = image.shape
+        D = conv_w.shape[0]
+        T = (H // patch) * (W // patch)
+        Kd = Cc * patch * patch
+        image = image.contiguous()
+        cols = _empty((B * T, Kd), act_dtype, image)
+        L.check(lib.segclip_im2col(L.ptr(image), L.ptr(cols), B, Cc, H, W, patch, 0, L.dt(cols), L.stream()), "im2col")
+        wc = wcast(conv_w.reshape(D, Kd), act_dtype)
+        x = _empty((B, T, D), torch.float32, image)
+        posc = pos.detach().contiguous()
+        p_gemm(cols, wc, x, T, D, Kd, (Kd, 1), (Kd, 1), D, residual=posc, ldr=D, r_off=D, nb1=B, bsA=(T * Kd, 0),
+               bsC=(T * D, 0), bsR=(0, 0))
+        ctx.save_for_backward(cols)
+        ctx.shape = (B, T, D, Kd, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape))
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (cols,) = ctx.saved_tensors
+        B, T, D, Kd, wshape, cshape, pshape = ctx.shape
+        dx = dx.contiguous()
+        dw = dcls = dpos = None
+        if ctx.needs_input_grad[1]:
+            dw = p_wgrad(dx.view(B * T, D), cols).view(wshape)
+        if ctx.needs_input_grad[2]:
+            dcls = torch.zeros(cshape, dtype=torch.float32, device=dx.device)
+        if ctx.needs_input_grad[3]:
+            dpos = torch.zeros(pshape, dtype=torch.float32, device=dx.device)
+            dpos[1:] = p_colsum(dx.view(B, T * D)).view(T, D)
+        return None, dw, dcls, dpos, None, None
+
+
+class EmbedFn(Function):
+    """token_embedding(ids) + positional_embedding[:L]  (modules/module_clip.py:109-112)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, pos):
+        B, Lq = ids.shape
+        V, D = table.shape
+        ids = ids.contiguous()
+        out = _empty((B, Lq, D), torch.float32, table)
+        posc = pos.detach().contiguous()
+        L.check(L.load().segclip_embed_fwd(L.ptr(ids), L.ptr(table), L.ptr(posc), L.ptr(out), B, Lq, D, V, L.stream()),
+                "embed_fwd")
+        ctx.save_for_backward(ids)
+        ctx.shape = (B, Lq, D, V, tuple(pos.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        B, Lq, D, V, pshape = ctx.shape
+        dout = dout.contiguous()
+        dtable = torch.zeros((V, D), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1] else None
+        dpos_l = _empty((Lq, D), torch.float32, dout) if ctx.needs_input_grad[2] else None
+        L.check(L.load().segclip_embed_bwd(L.ptr(ids), L.ptr(dout), L.ptr(dtable), L.ptr(dpos_l), B, Lq, D, V,
+                                           L.stream()), "embed_bwd")
+        dpos = None
+        if dpos_l is not None:
+            dpos = torch.zeros(pshape, dtype=torch.float32, device=dout.device)
+            dpos[:Lq] = dpos_l
+        return None, dtable, dpos
+
+
+class GatherRowsFn(Function):
+    """out[b,j,:] = src[b, idx[b,j], :] with unique idx per b (EOT pick, MAE keep / un-shuffle)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        B, Ts, D = src.shape
+        To = idx.shape[1]
+        src = src.contiguous()
+        idx = idx.contiguous()
+        out = _empty((B, To, D), src.dtype, src)
+        L.check(L.load().segclip_gather_rows(L.ptr(src), L.ptr(idx), L.ptr(out), B, Ts, To, D, L.dt(src), L.stream()),
+                "gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, Ts, To, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, Ts, To, D = ctx.shape
+        dout = dout.contiguous()
+        dsrc = torch.zeros((B, Ts, D), dtype=dout.dtype, device=dout.device)
+        L.check(L.load().segclip_scatter_rows(L.ptr(dout), L.ptr(idx), L.ptr(dsrc), B, Ts, To, D, L.dt(dout),
+                                              L.stream()), "scatter_rows")
+        return dsrc, None
+
+
+class AssignFn(Function):
+    """gumbel_softmax(hard=True, dim=centers) + soft assignment (modules/module_seg_vit.py:221-242,305-306).
+    logits (B,G,T) fp32, gumbel (B,G,T) fp32 or None (eval).  Returns hard (straight-through gradient),
+    soft (no grad, like the reference's use), idx uint8 (B,T)."""
+
+    @staticmethod
+    def forward(ctx, logits, gumbel, tau):
+        B, G, T = logits.shape
+        logits = logits.contiguous()
+        g = gumbel.contiguous() if gumbel is not None else None
+        y = torch.empty_like(logits)
+        soft = torch.empty_like(logits)
+        hard = torch.empty_like(logits)
+        idx = torch.empty((B, T), dtype=torch.uint8, device=logits.device)
+        counts = torch.empty((B, G), dtype=torch.float32, device=logits.device)
+        L.check(L.load().segclip_assign_fwd(L.ptr(logits), L.ptr(g), tau if g is not None else 1.0, L.ptr(y),
+                                            L.ptr(soft), L.ptr(idx), L.ptr(hard), L.ptr(counts), B, G, T, L.stream()),
+                "assign_fwd")
+        ctx.save_for_backward(y)
+        ctx.tau = tau if g is not None else 1.0
+        ctx.mark_non_differentiable(soft, idx)
+        return hard, soft, idx
+
+    @staticmethod
+    def backward(ctx, dhard, _dsoft, _didx):
+        (y,) = ctx.saved_tensors
+        B, G, T = y.shape
+        dhard = dhard.contiguous()
+        dl = torch.empty_like(y)
+        L.check(L.load().segclip_assign_bwd(L.ptr(dhard), L.ptr(y), ctx.tau, L.ptr(dl), B, G, T, L.stream()),
+                "assign_bwd")
+        return dl, None, None
+
+
+class L2NormFn(Function):
+    """x / ||x||  (modules/modeling.py:341-345)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        n = _empty((rows,), torch.float32, x)
+        L.check(L.load().segclip_l2norm_fwd(L.ptr(x), L.ptr(y), L.ptr(n), rows, cols, L.stream()), "l2norm_fwd")
+        ctx.save_for_backward(y, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, n = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.check(L.load().segclip_l2norm_bwd(L.ptr(dy), L.ptr(y), L.ptr(n), L.ptr(dx), y.shape[0], y.shape[1],
+                                            L.stream()), "l2norm_bwd")
+        return dx
+
+
+class CrossEntropyFn(Function):
+    """mean_i -log softmax(logits_i)[i + label_offset]  (nn.CrossEntropyLoss, modules/modeling.py:205-208)."""
+
+    @staticmethod
+    def forward(ctx, logits, label_offset):
+        logits = logits.contiguous()
+        rows, cols = logits.shape
+        lib = L.load()
+        lse = _empty((rows,), torch.float32, logits)
+        lr = _empty((rows,), torch.float32, logits)
+        L.check(lib.segclip_ce_fwd(L.ptr(logits), L.ptr(lse), L.ptr(lr), rows, cols, label_offset, L.stream()), "ce_fwd")
+        loss = _empty((), torch.float32, logits)
+        L.check(lib.segclip_reduce_sum(L.ptr(lr), L.ptr(loss), rows, 1.0 / rows, L.stream()), "reduce_sum")
+        ctx.save_for_backward(logits, lse)
+        ctx.label_offset = label_offset
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse = ctx.saved_tensors
+        rows, cols = logits.shape
+        g = g.contiguous().float()
+        dl = torch.empty_like(logits)
+        L.check(L.load().segclip_ce_bwd(L.ptr(logits), L.ptr(lse), L.ptr(g), 1.0, L.ptr(dl), rows, cols,
+                                        ctx.label_offset, L.stream()), "ce_bwd")
+        return dl, None
+
+
+class SuperpixelKLFn(Function):
+    """Symmetric KL between the hard assignment and its superpixel mean (modules/modeling.py:212-224)."""
+
+    @staticmethod
+    def forward(ctx, hard, seg):
+        B, G, T = hard.shape
+        hard = hard.contiguous()
+        seg = seg.contiguous().view(B, T)
+        lib = L.load()
+        lr = _empty((B,), torch.float32, hard)
+        dh = torch.empty_like(hard)
+        L.check(lib.segclip_superpixel_kl(L.ptr(hard), L.ptr(seg), L.ptr(lr), L.ptr(dh), B, G, T, L.stream()),
+                "superpixel_kl")
+        loss = _empty((), torch.float32, hard)
+        L.check(lib.segclip_reduce_sum(L.ptr(lr), L.ptr(loss), B, 1.0, L.stream()), "reduce_sum")
+        ctx.save_for_backward(dh)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dh,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        out = torch.empty_like(dh)
+        L.check(L.load().segclip_scale(L.ptr(dh), L.ptr(g), L.ptr(out), dh.numel(), L.stream()), "scale")
+        return out, None
+
+
+class MaskedMSEFn(Function):
+    """MAE reconstruction loss (modules/module_mae.py:322-328): pred (B,1+T,Dp) [row 0 = CLS, dropped],
+    target (B,T,Dp) fp32 (patchify), mask (B,1+T) fp32."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        B, T1, Dp = pred.shape
+        T = T1 - 1
+        pred = pred.contiguous()
+        lib = L.load()
+        lr = _empty((B * T,), torch.float32, pred)
+        L.check(lib.segclip_masked_mse_fwd(L.ptr(pred), L.ptr(target), L.ptr(mask), L.ptr(lr), B, T, Dp, L.dt(pred),
+                                           L.stream()), "masked_mse_fwd")
+        msum = _empty((), torch.float32, pred)
+        mflat = mask[:, 1:].contiguous()
+        L.check(lib.segclip_reduce_sum(L.ptr(mflat), L.ptr(msum), B * T, 1.0, L.stream()), "reduce_sum")
+        tot = _empty((), torch.float32, pred)
+        L.check(lib.segclip_reduce_sum(L.ptr(lr), L.ptr(tot), B * T, 1.0, L.stream()), "reduce_sum")
+        loss = _empty((), torch.float32, pred)
+        # loss = tot / msum  (single-element division, done by the scale kernel with 1/msum)
+        inv = torch.reciprocal(msum)
+        L.check(lib.segclip_scale(L.ptr(tot), L.ptr(inv), L.ptr(loss), 1, L.stream()), "scale")
+        ctx.save_for_backward(pred, target, mask, msum)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, mask, msum = ctx.saved_tensors
+        B, T1, Dp = pred.shape
+        g = g.contiguous().float()
+        dp = torch.empty_like(pred)
+        L.check(L.load().segclip_masked_mse_bwd(L.ptr(pred), L.ptr(target), L.ptr(mask), L.ptr(g), L.ptr(msum), 1.0,
+                                                L.ptr(dp), B, T1 - 1, Dp, L.dt(pred), L.stream()), "masked_mse_bwd")
+        return dp, None, None
+
+
+def patchify_target(image, patch):
+    """MAE target `patchify(imgs)` (modules/module_mae.py:18-29): (B,3,H,W) -> (B, T, p*p*3), fp32."""
+    B, Cc, H, W = image.shape
+    T = (H // patch) * (W // patch)
+    image = image.contiguous()
+    out = _empty((B, T, Cc * patch * patch), torch.float32, image)
+    L.check(L.load().segclip_im2col(L.ptr(image), L.ptr(out), B, Cc, H, W, patch, 1, L.F32, L.stream()), "im2col")
+    return out
+
+
+def mask_sort(noise, len_keep):
+    """MAE random masking indices (modules/module_clip_util.py:91-124, keep_cls=True).
+    Returns ids_shuffle, ids_restore (int64) and mask (fp32), bit-exact functions of `noise`."""
+    B, Lq = noise.shape
+    noise = noise.contiguous().float()
+    ids_shuffle = torch.empty((B, Lq), dtype=torch.int64, device=noise.device)
+    ids_restore = torch.empty((B, Lq), dtype=torch.int64, device=noise.device)
+    mask = torch.empty((B, Lq), dtype=torch.float32, device=noise.device)
+    L.check(L.load().segclip_mask_sort(L.ptr(noise), L.ptr(ids_shuffle), L.ptr(ids_restore), L.ptr(mask), B, Lq,
+                                       len_keep, L.stream()), "mask_sort")
+    return ids_shuffle, ids_restore, mask
+
+
+class AllGatherFn(Function):
+    """Differentiable rank-ordered all-gather of (B, ...) embeddings (dist_collect,
+    modules/util_module.py:180-190; diffdist semantics: all_gather forward, reduce-scatter(SUM)
+    backward).  On RCCL ("nccl" backend) both directions are ONE fused collective; the gloo branch
+    (CPU tests) uses all_reduce + own slice, which is the same arithmetic.  World size 1 = identity."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if ctx.world == 1:
+            return x
+        x = x.contiguous()
+        out = torch.empty((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.world == 1:
+            return g
+        g = g.contiguous()
+        n = g.shape[0] // ctx.world
+        if dist.get_backend() == "nccl":
+            out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
+            return out
+        g = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        r = dist.get_rank()
+        return g[r * n:(r + 1) * n].contiguous()
+
+
+def all_gather_embeddings(x):
+    return AllGatherFn.apply(x)

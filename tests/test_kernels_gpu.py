@@ -1,0 +1,392 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 reference of the same op (same seeded inputs),
+through the same ctypes boundary the product uses.  Integer outputs are compared bit-exactly."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from segclip_amd import ops  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+F32 = torch.float32
+
+
+def rnd(*shape, dtype=F32, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed + 131 * len(shape) + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float(err.max()):.3e}, "
+                                 f"ref max {float(ref.abs().max()):.3e}")
+
+
+TOL = {F32: (2e-5, 2e-5), BF: (2e-2, 2e-2)}
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 136, 72), (784, 2304, 768), (33, 8, 8), (1, 512, 512)])
+def test_gemm_nt_bias_act_residual(dtype, M, N, K):
+    if dtype == BF and K % 8:
+        pytest.skip("bf16 path needs K % 8 == 0")
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref_u = x.float() @ w.float().t() + b
+    rt, at = TOL[dtype]
+    y, _ = ops.p_linear(x, w, b)
+    close(y, ref_u, rt, at, "plain")
+    for act, f in ((ops.ACT_QUICK_GELU, lambda u: u * torch.sigmoid(1.702 * u)),
+                   (ops.ACT_GELU_ERF, lambda u: torch.nn.functional.gelu(u))):
+        y, u = ops.p_linear(x, w, b, act=act, residual=r, want_aux=True, out_dtype=F32)
+        close(u, ref_u, rt, at, "aux")
+        close(y, f(ref_u) + r, rt, at, f"act{act}+res")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 136, 72), (784, 768, 3072), (50, 64, 8)])
+def test_gemm_dgrad_wgrad_layouts(dtype, M, N, K):
+    """dgrad (k-strided B via the LDS transpose read) and wgrad (both operands k-strided)."""
+    if dtype == BF and (K % 8 or N % 8):
+        pytest.skip("bf16 path needs 16-byte rows")
+    dy, w, x = rnd(M, N, dtype=dtype, seed=5), rnd(N, K, dtype=dtype, seed=6, scale=N ** -0.5), rnd(M, K, dtype=dtype, seed=7)
+    rt, at = TOL[dtype]
+    dx = ops.p_dgrad(dy, w, dtype)
+    close(dx, dy.float() @ w.float(), rt, at * math.sqrt(N / 64 + 1), "dgrad")
+    dw = ops.p_wgrad(dy, x)
+    close(dw, dy.float().t() @ x.float(), rt, at * math.sqrt(M / 64 + 1), "wgrad")
+    u = rnd(M, K, dtype=dtype, seed=8)
+    du = ops.p_dgrad(dy, w, dtype, aux=u, act=ops.ACT_QUICK_GELU)
+    s = torch.sigmoid(1.702 * u.float())
+    close(du, (dy.float() @ w.float()) * (s * (1 + 1.702 * u.float() * (1 - s))), rt, at * math.sqrt(N / 64 + 1), "dgrad*dact")
+    # w stored (K_in, N_out) like visual.proj / text_projection
+    wkn = rnd(K, N, dtype=dtype, seed=9, scale=K ** -0.5)
+    y, _ = ops.p_linear(x, wkn, None, w_kn=True)
+    close(y, x.float() @ wkn.float(), rt, at * math.sqrt(K / 64 + 1), "w_kn fwd")
+    close(ops.p_dgrad(dy, wkn, dtype, w_kn=True), dy.float() @ wkn.float().t(), rt, at * math.sqrt(N / 64 + 1), "w_kn dgrad")
+    close(ops.p_wgrad(dy, x, w_kn=True), x.float().t() @ dy.float(), rt, at * math.sqrt(M / 64 + 1), "w_kn wgrad")
+
+
+def test_gemm_bf16_fp32_A_operand_and_splitk():
+    """fp32 residual-stream gradients as the A operand of the bf16 kernels; split-K wgrad (M >> tiles)."""
+    M, N, K = 6272, 256, 128
+    g = rnd(M, N, seed=11)
+    w, h = rnd(N, K, dtype=BF, seed=12, scale=N ** -0.5), rnd(M, K, dtype=BF, seed=13)
+    gb = g.to(BF).float()
+    close(ops.p_dgrad(g, w, BF), gb @ w.float(), 2e-2, 2e-2, "dgrad fp32 A")
+    close(ops.p_wgrad(g, h), gb.t() @ h.float(), 2e-2, 0.3, "wgrad fp32 A split-K")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_bmm_strided_autograd(dtype):
+    nb, M, N, K = 3, 8, 48, 64
+    A = rnd(nb, M, K, dtype=dtype, seed=21).requires_grad_()
+    Bm = rnd(nb, N, K, dtype=dtype, seed=22).requires_grad_()
+    C1 = ops.bmm(A, Bm, transB=True, out_dtype=F32)
+    ref = torch.einsum("bmk,bnk->bmn", A.float(), Bm.float())
+    rt, at = TOL[dtype]
+    close(C1, ref, rt, at * 4, "bmm NT")
+    go = rnd(nb, M, N, seed=23)
+    C1.backward(go)
+    close(A.grad, torch.einsum("bmn,bnk->bmk", go, Bm.float()), rt, at * 4, "bmm dA")
+    close(Bm.grad, torch.einsum("bmn,bmk->bnk", go, A.float()), rt, at * 4, "bmm dB")
+    A2 = rnd(nb, M, N, dtype=dtype, seed=24).requires_grad_()
+    B2 = rnd(nb, N, K, dtype=dtype, seed=25).requires_grad_()
+    C2 = ops.bmm(A2, B2, transB=False, out_dtype=F32)
+    close(C2, A2.float() @ B2.float(), rt, at * 4, "bmm NN")
+    go2 = rnd(nb, M, K, seed=26)
+    C2.backward(go2)
+    close(A2.grad, go2 @ B2.float().transpose(1, 2), rt, at * 4, "bmm NN dA")
+    close(B2.grad, A2.float().transpose(1, 2) @ go2, rt, at * 4, "bmm NN dB")
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("cols", [64, 128, 384, 512, 768, 1024])
+@pytest.mark.parametrize("xdt,ydt", [(F32, F32), (F32, BF), (BF, F32)])
+def test_layernorm_fwd_bwd(cols, xdt, ydt):
+    rows = 197
+    x = rnd(rows, cols, dtype=xdt, seed=31)
+    w, b = 1 + 0.1 * rnd(cols, seed=32), 0.1 * rnd(cols, seed=33)
+    y, mean, rstd = ops.p_ln_fwd(x, w, b, 1e-5, ydt)
+    xr = x.float().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr, (cols,), wr, br, 1e-5)
+    rt, at = (2e-5, 2e-5) if ydt == F32 else (1e-2, 1e-2)
+    close(y, ref, rt, at, "ln fwd")
+    dy = rnd(rows, cols, dtype=ydt, seed=34)
+    dres = rnd(rows, cols, dtype=F32, seed=35)
+    dx, dw, db = ops.p_ln_bwd(dy, x, w, mean, rstd, dres=dres, dx_dtype=F32)
+    ref.backward(dy.float())
+    close(dx, xr.grad + dres, 1e-4, 1e-4, "ln dx")
+    close(dw, wr.grad, 1e-4, 1e-3, "ln dgamma")
+    close(db, br.grad, 1e-4, 1e-3, "ln dbeta")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, H, causal):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    hd = D // H
+    qh, kh, vh = (t.float().reshape(B, -1, H, hd).permute(0, 2, 1, 3) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+    if causal:
+        s = s + torch.full((Tq, Tk), float("-inf"), device=s.device).triu_(1)
+    return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, D)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("B,T,H,hd,causal", [(2, 196, 12, 64, False), (3, 77, 8, 64, True), (2, 8, 2, 64, False),
+                                             (2, 197, 8, 48, False), (2, 17, 8, 8, False), (1, 48, 12, 64, False),
+                                             (2, 256, 2, 64, True)])
+def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
+    """Packed-QKV self attention exactly as ResBlockFn drives it (forward + backward)."""
+    D = H * hd
+    qkv = rnd(B * T, 3 * D, dtype=dtype, seed=41)
+    o = torch.empty(B * T, D, dtype=dtype, device=DEV)
+    s3 = (T * 3 * D, 3 * D)
+    d = ops._attn_desc(qkv, qkv, qkv, o, B, H, T, T, hd, s3, s3, s3, (T * D, D), 1 / math.sqrt(hd), causal, 0, D, 2 * D)
+    stats = ops.p_attn_fwd(d, qkv)
+    qr = qkv.float().view(B, T, 3, D).requires_grad_()
+    ref = _attn_ref(qr[:, :, 0], qr[:, :, 1], qr[:, :, 2], H, causal)
+    rt, at = (1e-4, 1e-4) if dtype == F32 else (2e-2, 2e-2)
+    close(o.view(B, T, D), ref, rt, at, "attn fwd")
+    do = rnd(B * T, D, dtype=dtype, seed=42)
+    dqkv = torch.zeros(B * T, 3 * D, dtype=dtype, device=DEV)
+    d = ops._attn_desc(qkv, qkv, qkv, o, B, H, T, T, hd, s3, s3, s3, (T * D, D), 1 / math.sqrt(hd), causal, 0, D, 2 * D)
+    ops.p_attn_bwd(d, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D)
+    ref.backward(do.float().view(B, T, D))
+    rt, at = (2e-4, 2e-4) if dtype == F32 else (3e-2, 3e-2)
+    close(dqkv.view(B, T, 3, D), qr.grad, rt, at, "attn bwd dqkv")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("mode", ["t18", "intended"])
+@pytest.mark.parametrize("B,G,T,H", [(4, 8, 196, 12), (3, 8, 48, 2)])
+def test_cross_attention_both_layouts(dtype, mode, B, G, T, H):
+    """Center cross-attention with the torch-1.8 key-buffer reinterpretation and the intended layout."""
+    D, S = H * 64, G + T
+    qp = rnd(B * G, D, dtype=dtype, seed=51).requires_grad_()
+    kv = rnd(B * S, 2 * D, dtype=dtype, seed=52).requires_grad_()
+    o = ops.CrossAttnFn.apply(qp, kv, B, G, S, H, mode)
+    qr = qp.detach().float().view(B, G, D).requires_grad_()
+    kvr = kv.detach().float().requires_grad_()
+    k3, v3 = kvr[:, :D], kvr[:, D:]
+    if mode == "t18":
+        k3, v3 = k3.reshape(S, B, D).permute(1, 0, 2), v3.reshape(S, B, D).permute(1, 0, 2)
+    else:
+        k3, v3 = k3.reshape(B, S, D), v3.reshape(B, S, D)
+    ref = _attn_ref(qr, k3, v3, H, False)
+    rt, at = (1e-4, 1e-4) if dtype == F32 else (2e-2, 2e-2)
+    close(o.view(B, G, D), ref, rt, at, "cross fwd")
+    do = rnd(B * G, D, dtype=dtype, seed=53)
+    o.backward(do)
+    ref.backward(do.float().view(B, G, D))
+    rt, at = (2e-4, 2e-4) if dtype == F32 else (3e-2, 3e-2)
+    close(qp.grad.view(B, G, D), qr.grad, rt, at, "cross dq")
+    close(kv.grad, kvr.grad, rt, at, "cross dkv")
+
+
+# ------------------------------------------------------------------------------------------ blocks
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("B,T,D,H,causal", [(2, 196, 128, 2, False), (3, 16, 64, 1, True), (2, 8, 768, 12, False)])
+def test_residual_block_autograd(dtype, B, T, D, H, causal):
+    """ResBlockFn (one autograd node, hand-written backward) vs torch autograd over plain ops."""
+    names = ["ln1w", "ln1b", "wqkv", "bqkv", "wo", "bo", "ln2w", "ln2b", "wfc", "bfc", "wpr", "bpr"]
+    shapes = [(D,), (D,), (3 * D, D), (3 * D,), (D, D), (D,), (D,), (D,), (4 * D, D), (4 * D,), (D, 4 * D), (D,)]
+    P = {}
+    for i, (n, s) in enumerate(zip(names, shapes)):
+        t = rnd(*s, seed=60 + i, scale=(s[-1] ** -0.5 if len(s) == 2 else 0.1))
+        if n in ("ln1w", "ln2w"):
+            t = 1 + t
+        P[n] = t.requires_grad_()
+    x = rnd(B, T, D, seed=59).requires_grad_()
+    y = ops.ResBlockFn.apply(x, *[P[n] for n in names], H, causal, ops.ACT_QUICK_GELU, 1e-5, dtype)
+    go = rnd(B, T, D, seed=58)
+    y.backward(go)
+    got = {n: P[n].grad.clone() for n in names}
+    gx = x.grad.clone()
+    for n in names:
+        P[n].grad = None
+    x.grad = None
+    ln = torch.nn.functional.layer_norm
+    y1 = ln(x, (D,), P["ln1w"], P["ln1b"], 1e-5)
+    qkv = y1 @ P["wqkv"].t() + P["bqkv"]
+    q, k, v = qkv.split(D, -1)
+    x1 = x + _attn_ref(q, k, v, H, causal) @ P["wo"].t() + P["bo"]
+    y2 = ln(x1, (D,), P["ln2w"], P["ln2b"], 1e-5)
+    u = y2 @ P["wfc"].t() + P["bfc"]
+    ref = x1 + (u * torch.sigmoid(1.702 * u)) @ P["wpr"].t() + P["bpr"]
+    ref.backward(go)
+    rt, at = (1e-4, 2e-4) if dtype == F32 else (5e-2, 5e-2)
+    close(y, ref, rt, at, "block fwd")
+    close(gx, x.grad, rt, at * 2, "block dx")
+    for n in names:
+        sc = float(P[n].grad.abs().max()) + 1e-6
+        close(got[n] / sc, P[n].grad / sc, rt, at, f"block d{n}")
+
+
+# ------------------------------------------------------------------------------------------ misc kernels
+def test_cast_colsum_act():
+    x = rnd(1000, 77, seed=71)
+    xb = ops.p_cast(x, BF)
+    assert torch.equal(xb, x.to(BF))
+    assert torch.equal(ops.p_cast(xb, F32), xb.float())
+    close(ops.p_colsum(x), x.sum(0), 1e-5, 1e-4, "colsum f32")
+    close(ops.p_colsum(xb), xb.float().sum(0), 1e-5, 1e-3, "colsum bf16")
+    xa = rnd(33, 65, seed=72).requires_grad_()
+    y = ops.ActFn.apply(xa, ops.ACT_QUICK_GELU)
+    y.backward(torch.ones_like(y))
+    xr = xa.detach().clone().requires_grad_()
+    r = xr * torch.sigmoid(1.702 * xr)
+    r.backward(torch.ones_like(r))
+    close(y, r, 1e-5, 1e-6, "qgelu")
+    close(xa.grad, xr.grad, 1e-5, 1e-6, "qgelu grad")
+
+
+def test_patch_embed_and_patchify():
+    B, p, res, D = 3, 16, 64, 128
+    img = rnd(B, 3, res, res, seed=81)
+    w = rnd(D, 3, p, p, seed=82, scale=0.05).requires_grad_()
+    cls, pos = rnd(D, seed=83).requires_grad_(), rnd(17, D, seed=84).requires_grad_()
+    x = ops.PatchEmbedFn.apply(img, w, cls, pos, p, F32)
+    ref = torch.nn.functional.conv2d(img, w, stride=p).reshape(B, D, -1).permute(0, 2, 1) + pos[1:]
+    close(x, ref, 1e-5, 1e-5, "patch embed")
+    go = rnd(B, 16, D, seed=85)
+    x.backward(go)
+    gw, gp = w.grad.clone(), pos.grad.clone()
+    w.grad = None
+    pos.grad = None
+    ref.backward(go)
+    close(gw, w.grad, 1e-4, 1e-4, "conv wgrad")
+    close(gp, pos.grad, 1e-5, 1e-5, "pos grad")
+    assert float(cls.grad.abs().max()) == 0.0
+    t = ops.patchify_target(img, p)
+    h = res // p
+    rt = torch.einsum("nchpwq->nhwpqc", img.reshape(B, 3, h, p, h, p)).reshape(B, h * h, p * p * 3)
+    assert torch.equal(t, rt)
+
+
+def test_embedding_gather_scatter():
+    B, Lq, D, V = 5, 16, 64, 300
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (B, Lq), generator=g).to(DEV)
+    table, pos = rnd(V, D, seed=91).requires_grad_(), rnd(Lq + 3, D, seed=92).requires_grad_()
+    out = ops.EmbedFn.apply(ids, table, pos)
+    ref = table[ids] + pos[:Lq]
+    assert torch.equal(out, ref)
+    go = rnd(B, Lq, D, seed=93)
+    out.backward(go)
+    gt, gp = table.grad.clone(), pos.grad.clone()
+    table.grad = None
+    pos.grad = None
+    ref.backward(go)
+    close(gt, table.grad, 1e-5, 1e-5, "dtable")
+    close(gp, pos.grad, 1e-5, 1e-5, "dpos")
+    src = rnd(B, Lq, D, seed=94).requires_grad_()
+    idx = torch.stack([torch.randperm(Lq, generator=g)[:7] for _ in range(B)]).to(DEV)
+    o = ops.GatherRowsFn.apply(src, idx)
+    r = torch.gather(src, 1, idx.unsqueeze(-1).expand(-1, -1, D))
+    assert torch.equal(o, r)
+    go = rnd(B, 7, D, seed=95)
+    o.backward(go)
+    g1 = src.grad.clone()
+    src.grad = None
+    r.backward(go)
+    assert torch.equal(g1, src.grad)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_center_assignment_bit_exact(train):
+    B, G, T = 4, 8, 196
+    logits = rnd(B, G, T, seed=101, scale=5.0).requires_grad_()
+    gum = rnd(B, G, T, seed=102) if train else None
+    hard, soft, idx = ops.AssignFn.apply(logits, gum, 0.9)
+    lr = logits.detach().clone().requires_grad_()
+    y = ((lr + gum) / 0.9).softmax(1) if train else lr.softmax(1)
+    index = y.max(1, keepdim=True)[1]
+    y_hard = torch.zeros_like(lr).scatter_(1, index, 1.0)
+    ref = y_hard - y.detach() + y
+    assert torch.equal(idx.long(), index.squeeze(1)), "argmax over the 8 centers must be bit exact"
+    assert torch.equal(hard, y_hard)
+    close(soft, lr.softmax(1), 1e-5, 1e-6, "soft")
+    go = rnd(B, G, T, seed=103)
+    hard.backward(go)
+    ref.backward(go)
+    close(logits.grad, lr.grad, 1e-4, 1e-6, "straight-through grad")
+
+
+def test_contrastive_pieces():
+    B, E, W = 16, 64, 4
+    x = rnd(B, E, seed=111).requires_grad_()
+    y = ops.L2NormFn.apply(x)
+    xr = x.detach().clone().requires_grad_()
+    r = xr / xr.norm(dim=-1, keepdim=True)
+    go = rnd(B, E, seed=112)
+    y.backward(go)
+    r.backward(go)
+    close(y, r, 1e-5, 1e-6, "l2norm")
+    close(x.grad, xr.grad, 1e-4, 1e-6, "l2norm grad")
+    logits = rnd(B, B * W, seed=113, scale=4.0).requires_grad_()
+    off = 2 * B
+    loss = ops.CrossEntropyFn.apply(logits, off)
+    lr = logits.detach().clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(lr, torch.arange(B, device=DEV) + off)
+    (loss * 0.5).backward()
+    (ref * 0.5).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    close(logits.grad, lr.grad, 1e-4, 1e-7, "ce grad")
+
+
+def test_superpixel_kl_and_masked_mse():
+    B, G, T = 3, 8, 16
+    g = torch.Generator().manual_seed(7)
+    idx = torch.randint(0, G, (B, T), generator=g).to(DEV)
+    hard0 = torch.zeros(B, G, T, device=DEV).scatter_(1, idx.unsqueeze(1), 1.0)
+    seg = torch.randint(0, 4, (B, T), generator=g).to(DEV)
+    hard = hard0.clone().requires_grad_()
+    loss = ops.SuperpixelKLFn.apply(hard, seg)
+    hr = hard0.clone().requires_grad_()
+    h = hr.permute(0, 2, 1)
+    eq = ((seg.unsqueeze(-1) - seg.unsqueeze(-2)) == 0).float()
+    cm = (eq @ h) / torch.clamp_min(eq.sum(-1, keepdim=True), 1.0)
+    F = torch.nn.functional
+    coef = float(B * T * G)
+    ref = (F.kl_div(F.log_softmax(h, -1), F.softmax(cm, -1), reduction="sum") / coef
+           + F.kl_div(F.log_softmax(cm, -1), F.softmax(h, -1), reduction="sum") / coef) / 2
+    (loss * 3).backward()
+    (ref * 3).backward()
+    assert abs(float(loss) - float(ref)) < 1e-6, (float(loss), float(ref))
+    close(hard.grad, hr.grad, 1e-3, 1e-7, "kl dhard")
+    Dp = 48
+    pred = rnd(B, T + 1, Dp, seed=121).requires_grad_()
+    target = rnd(B, T, Dp, seed=122)
+    mask = (torch.rand(B, T + 1, generator=g) > 0.3).float().to(DEV)
+    l2 = ops.MaskedMSEFn.apply(pred, target, mask)
+    pr = pred.detach().clone().requires_grad_()
+    r2 = (((pr[:, 1:] - target) ** 2).mean(-1) * mask[:, 1:]).sum() / mask[:, 1:].sum()
+    l2.backward()
+    r2.backward()
+    assert abs(float(l2) - float(r2)) < 1e-5
+    close(pred.grad, pr.grad, 1e-4, 1e-7, "mse grad")
+
+
+def test_mask_sort_bit_exact():
+    B, Lq = 6, 197
+    g = torch.Generator().manual_seed(3)
+    noise = torch.rand(B, Lq, generator=g).to(DEV)
+    ids_shuffle, ids_restore, mask = ops.mask_sort(noise, int(Lq * 0.25))
+    n2 = noise.clone()
+    n2[:, 0] = -1
+    rs = torch.argsort(n2, dim=1)
+    rr = torch.argsort(rs, dim=1)
+    assert torch.equal(ids_shuffle, rs) and torch.equal(ids_restore, rr)
+    m = torch.ones(B, Lq, device=DEV)
+    m[:, :int(Lq * 0.25)] = 0
+    assert torch.equal(mask, torch.gather(m, 1, rr))

@@ -1,0 +1,149 @@
+"""GPU: the whole hot path (segclip_amd.modules.modeling.SegCLIP through the C-ABI kernels) against
+(a) the golden vectors produced by the REAL reference and (b) the CPU oracle on the same seeded inputs.
+Tolerances: exact-f32 mode |d loss|, |d logits| <= 1e-3 (north_star), integer paths bit-exact; bf16
+mode is reported against its own looser bound."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import segclip_amd  # noqa: E402
+from segclip_amd import synth  # noqa: E402
+from tests.helpers import FULL_FLAGS, load_golden, noise_items  # noqa: E402
+
+DEV = "cuda"
+
+
+def run_model(spec_name, B, seed, mode, dtype, flags=FULL_FLAGS, batch_slice=None, rank=0, world=1):
+    spec = synth.SPECS[spec_name]
+    segclip_amd.set_compute_dtype(dtype)
+    segclip_amd.set_cross_mode(mode)
+    try:
+        model, args = synth.build_model(spec, flags, rank=rank, world_size=world, device=DEV)
+        batch = synth.synthetic_batch(spec, B, seed=seed, device=DEV)
+        noise = synth.synthetic_noise(spec, B, seed=seed, device=DEV)
+        with segclip_amd.noise_injection(noise_items(noise, flags)):
+            loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"],
+                         image_seg=batch.get("image_seg"))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
+        segclip_amd.set_cross_mode("t18")
+    return model, loss
+
+
+def check_against_golden(model, loss, g, tol_loss, tol_logit, grad_rtol, exact_int=True):
+    assert abs(float(loss) - float(g["loss"])) <= tol_loss, (float(loss), float(g["loss"]))
+    L = model.last_losses
+    assert abs(float(L["contrastive"]) - float(g["loss_contrastive"])) <= tol_loss
+    assert abs(float(L["kl"]) - float(g["loss_kl"])) <= tol_loss
+    assert abs(float(L["mae"]) - float(g["loss_mae"])) <= tol_loss
+    t2v, v2t = model.last_logits
+    assert float((t2v.cpu() - torch.from_numpy(g["t2v"])).abs().max()) <= tol_logit
+    assert float((v2t.cpu() - torch.from_numpy(g["v2t"])).abs().max()) <= tol_logit
+    if exact_int:
+        assert np.array_equal(model.last_mid_states["hard_idx"].cpu().numpy().astype(np.int64), g["hard_idx"])
+        mask, ids_restore, mid_mae = model.last_mae
+        assert np.array_equal(ids_restore.cpu().numpy(), g["ids_restore"])
+        assert np.array_equal(mask.cpu().numpy(), g["mae_mask"])
+        assert np.array_equal(mid_mae["hard_idx"].cpu().numpy().astype(np.int64), g["mae_hard_idx"])
+    P = dict(model.named_parameters())
+    worst = 0.0
+    for n, ref in zip(g["grad_names"].tolist(), g["grad_norms"]):
+        assert P[n].grad is not None, n
+        got = float(P[n].grad.double().norm())
+        worst = max(worst, abs(got - ref) / max(ref, 1e-6 * (1 + ref)))
+        assert abs(got - ref) <= grad_rtol * max(ref, 1e-4), (n, got, ref)
+    for n in g["none_grad"].tolist():
+        assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0, n
+    return worst
+
+
+@pytest.mark.parametrize("mode", ["t18", "intended"])
+def test_tiny_f32_matches_reference_golden(mode):
+    g = load_golden(f"tiny_{mode}.npz")
+    model, loss = run_model("tiny", int(g["B"]), int(g["seed"]), mode, torch.float32)
+    check_against_golden(model, loss, g, 1e-4, 1e-3, 5e-3)
+    for k in g.files:
+        if k.startswith("grad::"):
+            got = dict(model.named_parameters())[k[6:]].grad.cpu().numpy()
+            np.testing.assert_allclose(got, g[k], rtol=5e-3, atol=1e-5, err_msg=k)
+    assert float(model.clip.visual.class_embedding.grad.abs().max()) == 0.0
+
+
+def test_vitb16_b4_f32_matches_reference_golden():
+    """BASELINE.json config 1 on the GPU: ViT-B/16 + 77-token text, batch 4, full loss."""
+    g = load_golden("vitb16_b4_t18.npz")
+    model, loss = run_model("vitb16", int(g["B"]), int(g["seed"]), "t18", torch.float32)
+    check_against_golden(model, loss, g, 1e-3, 1e-3, 2e-2)
+
+
+def test_tiny_f32_matches_cpu_oracle_fresh_seed():
+    """Same seeded inputs through the HIP path and the CPU oracle (not a stored fixture)."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["tiny"]
+    B, seed = 5, 11
+    model, loss = run_model("tiny", B, seed, "t18", torch.float32)
+    P = oracle_params(spec, model_param_shapes(spec, FULL_FLAGS))
+    lo, aux = so.segclip_forward(synth.synthetic_batch(spec, B, seed=seed), P, spec, synth.synthetic_noise(spec, B, seed=seed),
+                                 FULL_FLAGS)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) <= 1e-4
+    assert torch.equal(model.last_mid_states["hard_idx"].cpu().long(), aux["hard_idx"])
+    assert float((model.last_logits[0].cpu() - aux["t2v"].detach()).abs().max()) <= 1e-3
+    for n, p in model.named_parameters():
+        if P[n].grad is None:
+            continue
+        ref = P[n].grad
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 5e-3 * float(ref.abs().max()) + 1e-6, (n, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("spec_name,B", [("tiny", 3), ("vitb16", 4)])
+def test_bf16_mode_error_is_bounded(spec_name, B):
+    """Throughput mode: reported separately from the 1e-3 gate (bf16 through 24 blocks)."""
+    g = load_golden("tiny_t18.npz" if spec_name == "tiny" else "vitb16_b4_t18.npz")
+    model, loss = run_model(spec_name, int(g["B"]), int(g["seed"]), "t18", torch.bfloat16)
+    print(f"\n[bf16 {spec_name}] loss {float(loss):.5f} vs ref {float(g['loss']):.5f}; "
+          f"max |dlogit| {float((model.last_logits[0].cpu() - torch.from_numpy(g['t2v'])).abs().max()):.4f}; "
+          f"hard_idx agreement {float((model.last_mid_states['hard_idx'].cpu().numpy() == g['hard_idx']).mean()):.4f}")
+    assert abs(float(loss) - float(g["loss"])) <= 0.08
+    assert float((model.last_logits[0].cpu() - torch.from_numpy(g["t2v"])).abs().max()) <= 0.5
+    assert torch.isfinite(torch.stack([p.grad.float().norm() for p in model.parameters() if p.grad is not None])).all()
+
+
+def test_full_size_properties_bf16():
+    """BASELINE.json config 2 shape (ViT-B/16, B=256, contrastive only): size-independent properties."""
+    B = 256
+    spec = synth.SPECS["vitb16"]
+    segclip_amd.set_compute_dtype(torch.bfloat16)
+    segclip_amd.set_cross_mode("intended")
+    try:
+        model, _ = synth.build_model(spec, {}, device=DEV)
+        batch = synth.synthetic_batch(spec, B, seed=3, device=DEV, with_seg=False)
+        noise = synth.synthetic_noise(spec, B, seed=3, device=DEV)
+        with segclip_amd.noise_injection([("gumbel", noise["gumbel_main"])]):
+            loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"])
+        loss.backward()
+        t2v, v2t = model.last_logits
+        hard = model.last_mid_states["attns"][0]["hard_attn"]
+        # every patch assigned to exactly one center; logits bounded by the clamped scale; t2v == v2t^T at W=1
+        assert torch.equal(hard.sum(1), torch.ones_like(hard.sum(1)))
+        assert float(t2v.abs().max()) <= 100.0 * 1.01
+        assert float((t2v - v2t.t()).abs().max()) <= 1e-4
+        assert torch.isfinite(loss) and abs(float(loss) - float(np.log(B))) < 3.0
+        # batch-permutation equivariance (each sample attends only to itself in "intended" mode)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+        with segclip_amd.noise_injection([("gumbel", noise["gumbel_main"][perm])]):
+            loss2 = model(batch["input_ids"][perm], batch["segment_ids"][perm], batch["input_mask"][perm],
+                          batch["image"][perm])
+        t2v2 = model.last_logits[0]
+        assert float((t2v2 - t2v[perm][:, perm]).abs().max()) <= 2e-2
+        assert abs(float(loss2) - float(loss)) <= 1e-3
+        assert float(model.clip.visual.class_embedding.grad.abs().max()) == 0.0
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
+        segclip_amd.set_cross_mode("t18")
