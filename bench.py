@@ -1,0 +1,164 @@
+"""bench.py - image-text pairs/s, forward+backward, of the SegCLIP contrastive hot path on MI355X.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through
+torch.distributed.run, one rank per GPU over RCCL.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1] at N=1, configs[2] at N=8): ViT-B/16 224^2 + 77-token text,
+contrastive loss only, per-GPU batch 256 (weak scaling: global batch 256*N, 2048 at N=8), bf16 MFMA
+kernels, fp32 master weights, synthetic images/captions, closed-form random weights.  A step is one
+forward + backward (loss -> every parameter gradient, incl. the embedding all-gather and, for N>1, the
+DDP gradient all-reduce); the optimizer step is excluded, as in BASELINE.json's metric definition.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import segclip_amd  # noqa: E402
+from segclip_amd import ops, synth  # noqa: E402
+
+GF_PER_PAIR_FWD_BWD = 109.675  # ViT-B/16 contrastive-only, contractions only
+PEAK_BF16_TF = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--spec", default="vitb16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--full-loss", action="store_true", help="configs[3]: + superpixel-KL + MAE")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """Reference CPU path (the oracle = validated CPU restatement of the reference) on this host's cores:
+    BASELINE.json configs[0]: ViT-B/16 + 77-token text, batch 4, contrastive only, fwd+bwd."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["vitb16"]
+    cores = min(os.cpu_count() or 1, 32)  # torch CPU eager stops scaling (and thrashes) far below 256 threads
+    torch.set_num_threads(cores)
+    P = oracle_params(spec, model_param_shapes(spec, {}))
+    B = 4
+    batch = synth.synthetic_batch(spec, B, seed=2, with_seg=False)
+    noise = synth.synthetic_noise(spec, B, seed=2)
+    best = None
+    for it in range(2):  # 1 warm-up + 1 timed (bounded: the GPU box is billed for this too)
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        loss, _ = so.segclip_forward(batch, P, spec, noise, {})
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    return {"value": round(B / best, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU restatement of the reference, torch {torch.__version__} fp32), ViT-B/16 B=4 "
+                      f"contrastive-only fwd+bwd, 1 timed step after 1 warm-up, {best:.2f} s/step",
+            "loss": round(float(loss), 6)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    spec = synth.SPECS[a.spec]
+    flags = dict(use_seglabel=True, use_vision_mae_recon=True) if a.full_loss else {}
+    segclip_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    torch.manual_seed(1234 + rank)
+    model, targs = synth.build_model(spec, flags, rank=rank, world_size=world, device=dev)
+    # the reference driver freezes these two (main_task_align.py:436-441)
+    model.clip.visual.conv1.weight.requires_grad_(False)
+    model.clip.visual.positional_embedding.requires_grad_(False)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                        find_unused_parameters=True, gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=64)
+    batch = synth.synthetic_batch(spec, a.batch, seed=100 + rank, device=dev, with_seg=a.full_loss)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        loss = net(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"],
+                   image_seg=batch.get("image_seg"))
+        loss.backward()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+    ms = elapsed / a.steps * 1e3
+    pairs = a.batch * world * a.steps / elapsed
+
+    roofline = None
+    if not a.no_roofline and a.dtype == "bf16":
+        # dominant kernel = gemm_bf16_kernel (all layouts): per-launch HIP-event timing on the launch stream
+        ops._GemmProfile.start()
+        step()
+        rec = [r for r in ops._GemmProfile.stop() if r[2]]
+        tsum = sum(r[0] for r in rec)
+        fsum = sum(r[1] for r in rec)
+        big = [r for r in rec if r[1] >= 1e11]
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(fsum / tsum / 1e12, 1),
+                    "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(fsum / tsum / 1e12 / PEAK_BF16_TF, 4),
+                    "traffic": None, "launches_per_step": len(rec), "avg_launch_us": round(tsum / len(rec) * 1e6, 1),
+                    "gemm_share_of_step": round(tsum * 1e3 / ms, 3),
+                    "large_gemm_tflops": round(sum(r[1] for r in big) / max(sum(r[0] for r in big), 1e-9) / 1e12, 1),
+                    "step_frac": round(pairs / world * GF_PER_PAIR_FWD_BWD / 1e3 / PEAK_BF16_TF, 4)}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        out = {"metric": "image-text pairs/s fwd+bwd, ViT-B/16 224^2, per-GPU batch 256 (global 2048 at 8 GPUs)",
+               "value": round(pairs, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": ("BASELINE configs[3]: ViT-B/16 224^2 + 77-token text, full SegCLIP loss"
+                                       if a.full_loss else
+                                       "BASELINE configs[1]/[2]: ViT-B/16 224^2 + 77-token text, contrastive loss only"),
+                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "cross_mode": segclip_amd.config.cross_mode, "loss": round(loss_val, 5)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

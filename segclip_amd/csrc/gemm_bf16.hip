@@ -9,12 +9,15 @@
 // ((row>>1)&7): conflict-free ds_read_b128 for the 32x32x16 fragment).  k-strided operands are
 // staged as [64 k][128 rows] (pitch 160) and the fragment is built with the gfx950 LDS
 // transpose read ds_read_b64_tr_b16, so neither W nor the activations are ever transposed in HBM.
+// The A operand may be fp32 in HBM (residual-stream gradients): it is rounded to bf16 while staging.
 //
 // Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 acc VGPRs).
-// Register-staged double buffer: global loads of tile t+1 are issued before the MFMAs of tile t and
-// written to the other LDS buffer afterwards (one barrier per K-step).  Workgroup ids are remapped so
-// each XCD walks a contiguous run of tiles (shared A panel stays in that XCD's L2).
-#include "common.h"
+// Register-staged double buffer: the 8 global loads of tile t+1 are issued before the MFMAs of tile t
+// and stay in flight under them; conversion / zero-masking / ds_write happen after the MFMAs (one
+// barrier per K-step).  All loads are unconditional from clamped addresses (no divergent branch around a
+// load).  Workgroup ids are remapped so each XCD walks a contiguous run of tiles (A panel reuse in its L2).
+// Split-K (grid.y) for the wgrad shapes, combined by a deterministic slab reduction.
+#include "gemm_bf16_common.h"
 
 namespace {
 
@@ -23,114 +26,123 @@ constexpr int KS_PITCH = 160;                 // elements per k-row of a k-strid
 constexpr int SZ_DIRECT = BM * BK * 2;        // 16384 B
 constexpr int SZ_KS = BK * KS_PITCH * 2;      // 20480 B
 
-struct Args {
-  const void* A; const bf16_t* B; void* C;
-  const float* bias; const void* residual; void* aux;
-  int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
-  int64_t nb2, bsA1, bsA2, bsB1, bsB2, bsC1, bsC2, bsR1, bsR2;
-  int c_dtype, r_dtype, act, mul_dact; float alpha;
-  int nbx, nby;
-  int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
-};
+// raw staged data of one operand tile: 4 chunks of 8 elements per thread (+ validity bits)
+template <typename T> struct Stage;
+template <> struct Stage<bf16_t> { u32x4 v[4]; unsigned ok; };
+template <> struct Stage<float> { f32x4 lo[4], hi[4]; unsigned ok; };
 
-struct Stage { u32x4 v[4]; };
+template <typename T> __device__ __forceinline__ void ld8(Stage<T>& s, int i, const T* p);
+template <> __device__ __forceinline__ void ld8<bf16_t>(Stage<bf16_t>& s, int i, const bf16_t* p) {
+  s.v[i] = *reinterpret_cast<const u32x4*>(p);
+}
+template <> __device__ __forceinline__ void ld8<float>(Stage<float>& s, int i, const float* p) {
+  s.lo[i] = *reinterpret_cast<const f32x4*>(p);
+  s.hi[i] = *reinterpret_cast<const f32x4*>(p + 4);
+}
+__device__ __forceinline__ u32x4 chunk(const Stage<bf16_t>& s, int i) {
+  return ((s.ok >> i) & 1u) ? s.v[i] : u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ u32x4 chunk(const Stage<float>& s, int i) {
+  u32x4 v;
+  v[0] = pack2bf(s.lo[i][0], s.lo[i][1]); v[1] = pack2bf(s.lo[i][2], s.lo[i][3]);
+  v[2] = pack2bf(s.hi[i][0], s.hi[i][1]); v[3] = pack2bf(s.hi[i][2], s.hi[i][3]);
+  return ((s.ok >> i) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
+}
 
-// ---- global -> registers --------------------------------------------------------------------
+// ---- global -> registers (FAST: 16-byte aligned rows, branch-free) ----------------------------
 // k-contiguous operand: X(row,k) = X[row*ld + k]; thread -> chunk c = tid&7 (8 k), rows tid>>3 + 32*i
 template <typename T>
-__device__ __forceinline__ void gload_direct(Stage& s, const T* __restrict__ X, int64_t ld, int64_t row0,
-                                             int64_t nrows, int64_t k0, int64_t K, int tid) {
-  const int c = tid & 7;
-  const int64_t k = k0 + c * 8;
+__device__ __forceinline__ void gload_direct_fast(Stage<T>& s, const T* __restrict__ X, int64_t ld, int64_t row0,
+                                                  int64_t nrows, int64_t k0, int64_t K, int tid) {
+  const int64_t k = k0 + (tid & 7) * 8;
+  const bool kok = k < K;
+  const int64_t kc = kok ? k : K - 8;
+  unsigned ok = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t r = row0 + (tid >> 3) + 32 * i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < nrows && k < K) {
-      const T* p = X + r * ld + k;
-      if constexpr (sizeof(T) == 2) {
-        if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-          v = *reinterpret_cast<const u32x4*>(p);
-        } else {
-          bf16_t e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = (k + j < K) ? reinterpret_cast<const bf16_t*>(p)[j] : (bf16_t)0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
-        }
-      } else {
-        float e[8];
-        if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-          e[0] = a[0]; e[1] = a[1]; e[2] = a[2]; e[3] = a[3]; e[4] = b[0]; e[5] = b[1]; e[6] = b[2]; e[7] = b[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = (k + j < K) ? (float)p[j] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = pack2bf(e[2 * j], e[2 * j + 1]);
-      }
-    }
-    s.v[i] = v;
+    ok |= (unsigned)(kok && r < nrows) << i;
+    ld8<T>(s, i, X + (r < nrows ? r : nrows - 1) * ld + kc);
   }
+  s.ok = ok;
 }
-
 // k-strided operand: X(row,k) = X[k*ld + row]; thread -> chunk c = tid&15 (8 rows), k = tid>>4 + 16*i
 template <typename T>
-__device__ __forceinline__ void gload_ks(Stage& s, const T* __restrict__ X, int64_t ld, int64_t row0,
-                                         int64_t nrows, int64_t k0, int64_t K, int tid) {
-  const int c = tid & 15;
-  const int64_t r = row0 + c * 8;
+__device__ __forceinline__ void gload_ks_fast(Stage<T>& s, const T* __restrict__ X, int64_t ld, int64_t row0,
+                                              int64_t nrows, int64_t k0, int64_t K, int tid) {
+  const int64_t r = row0 + (tid & 15) * 8;
+  const bool rok = r < nrows;
+  const int64_t rc = rok ? r : nrows - 8;
+  unsigned ok = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t k = k0 + (tid >> 4) + 16 * i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (k < K && r < nrows) {
-      const T* p = X + k * ld + r;
-      if constexpr (sizeof(T) == 2) {
-        if (r + 8 <= nrows && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-          v = *reinterpret_cast<const u32x4*>(p);
-        } else {
-          bf16_t e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = (r + j < nrows) ? reinterpret_cast<const bf16_t*>(p)[j] : (bf16_t)0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
-        }
-      } else {
-        float e[8];
-        if (r + 8 <= nrows && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-          e[0] = a[0]; e[1] = a[1]; e[2] = a[2]; e[3] = a[3]; e[4] = b[0]; e[5] = b[1]; e[6] = b[2]; e[7] = b[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = (r + j < nrows) ? (float)p[j] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = pack2bf(e[2 * j], e[2 * j + 1]);
-      }
-    }
-    s.v[i] = v;
+    ok |= (unsigned)(rok && k < K) << i;
+    ld8<T>(s, i, X + (k < K ? k : K - 1) * ld + rc);
   }
+  s.ok = ok;
+}
+
+// ---- global -> registers (generic: any alignment / ragged K; element-wise guarded) -------------
+template <typename T> __device__ __forceinline__ void put8(Stage<T>& s, int i, const float* e);
+template <> __device__ __forceinline__ void put8<bf16_t>(Stage<bf16_t>& s, int i, const float* e) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s.v[i][j] = pack2bf(e[2 * j], e[2 * j + 1]);
+}
+template <> __device__ __forceinline__ void put8<float>(Stage<float>& s, int i, const float* e) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s.lo[i][j] = e[j]; s.hi[i][j] = e[4 + j]; }
+}
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+
+template <typename T>
+__device__ __forceinline__ void gload_direct_slow(Stage<T>& s, const T* __restrict__ X, int64_t ld, int64_t row0,
+                                                  int64_t nrows, int64_t k0, int64_t K, int tid) {
+  const int64_t k = k0 + (tid & 7) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = row0 + (tid >> 3) + 32 * i;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (r < nrows && k + j < K) ? ldf<T>(X + r * ld + k + j) : 0.f;
+    put8<T>(s, i, e);
+  }
+  s.ok = 0xF;
+}
+template <typename T>
+__device__ __forceinline__ void gload_ks_slow(Stage<T>& s, const T* __restrict__ X, int64_t ld, int64_t row0,
+                                              int64_t nrows, int64_t k0, int64_t K, int tid) {
+  const int64_t r = row0 + (tid & 15) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t k = k0 + (tid >> 4) + 16 * i;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (k < K && r + j < nrows) ? ldf<T>(X + k * ld + r + j) : 0.f;
+    put8<T>(s, i, e);
+  }
+  s.ok = 0xF;
 }
 
 // ---- registers -> LDS -----------------------------------------------------------------------
-__device__ __forceinline__ void sstore_direct(const Stage& s, char* lds, int tid) {
+template <typename T>
+__device__ __forceinline__ void sstore_direct(const Stage<T>& s, char* lds, int tid) {
   const int c = tid & 7;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (tid >> 3) + 32 * i;
-    *reinterpret_cast<u32x4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = s.v[i];
+    *reinterpret_cast<u32x4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = chunk(s, i);
   }
 }
-__device__ __forceinline__ void sstore_ks(const Stage& s, char* lds, int tid) {
+template <typename T>
+__device__ __forceinline__ void sstore_ks(const Stage<T>& s, char* lds, int tid) {
   const int c = tid & 15;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = (tid >> 4) + 16 * i;
-    *reinterpret_cast<u32x4*>(lds + k * (KS_PITCH * 2) + c * 16) = s.v[i];
+    *reinterpret_cast<u32x4*>(lds + k * (KS_PITCH * 2) + c * 16) = chunk(s, i);
   }
 }
 
@@ -157,7 +169,7 @@ __device__ __forceinline__ bf16x8_t frag_ks(const char* lds, int rbase, int kc, 
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <bool A_KS, bool B_KS, bool A_F32>
+template <bool A_KS, bool B_KS, bool A_F32, bool FAST>
 __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
   constexpr int SZA = A_KS ? SZ_KS : SZ_DIRECT;
   constexpr int SZB = B_KS ? SZ_KS : SZ_DIRECT;
@@ -185,12 +197,24 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stage sa, sb;
+  const int64_t kbeg = (int64_t)blockIdx.y * g.kper;
+  const int64_t kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+  const int64_t nk = (kend - kbeg + BK - 1) / BK;
+
+  Stage<TA> sa;
+  Stage<bf16_t> sb;
   auto gload = [&](int64_t k0) {
-    if constexpr (A_KS) gload_ks<TA>(sa, A, g.lda, m0, g.M, k0, g.K, tid);
-    else gload_direct<TA>(sa, A, g.lda, m0, g.M, k0, g.K, tid);
-    if constexpr (B_KS) gload_ks<bf16_t>(sb, B, g.ldb, n0, g.N, k0, g.K, tid);
-    else gload_direct<bf16_t>(sb, B, g.ldb, n0, g.N, k0, g.K, tid);
+    if constexpr (FAST) {
+      if constexpr (A_KS) gload_ks_fast<TA>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+      else gload_direct_fast<TA>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+      if constexpr (B_KS) gload_ks_fast<bf16_t>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+      else gload_direct_fast<bf16_t>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+    } else {
+      if constexpr (A_KS) gload_ks_slow<TA>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+      else gload_direct_slow<TA>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+      if constexpr (B_KS) gload_ks_slow<bf16_t>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+      else gload_direct_slow<bf16_t>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+    }
   };
   auto sstore = [&](int buf) {
     char* la = smem + buf * (SZA + SZB);
@@ -199,11 +223,6 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
     if constexpr (B_KS) sstore_ks(sb, lb, tid); else sstore_direct(sb, lb, tid);
   };
 
-  const int64_t kbeg = (int64_t)blockIdx.y * g.kper;
-  const int64_t kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
-  const int64_t nk = (kend - kbeg + BK - 1) / BK;
-  const int64_t Kreal = g.K;
-  g.K = kend;  // loaders zero-fill k >= g.K
   gload(kbeg);
   sstore(0);
   __syncthreads();
@@ -231,10 +250,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
     __syncthreads();
   }
 
-  // epilogue.  C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int li = lane & 31, lk = lane >> 5;
-  (void)Kreal;
+  // C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (g.splits > 1) {
+    const int li = lane & 31, lk = lane >> 5;
     float* slab = g.slab + ((int64_t)blockIdx.y * gridDim.z + z) * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -250,40 +268,14 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
       }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 32 + li;
-      if (n >= g.N) continue;
-      const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= g.M) continue;
-        float v = g.alpha * acc[i][j][r];
-        if (g.mul_dact) {
-          const int64_t o = coff + m * g.ldaux + n;
-          const float u = g.c_dtype == SEGCLIP_BF16 ? bf2f(((const bf16_t*)g.aux)[o]) : ((const float*)g.aux)[o];
-          v *= apply_act_grad(g.act, u);
-        } else {
-          v += bv;
-          if (g.act != SEGCLIP_ACT_NONE) {
-            if (g.aux) {
-              const int64_t o = coff + m * g.ldaux + n;
-              if (g.c_dtype == SEGCLIP_BF16) ((bf16_t*)g.aux)[o] = f2bf(v); else ((float*)g.aux)[o] = v;
-            }
-            v = apply_act(g.act, v);
-          }
-          if (g.residual) {
-            const int64_t o = roff + m * g.ldr + n;
-            v += g.r_dtype == SEGCLIP_BF16 ? bf2f(((const bf16_t*)g.residual)[o]) : ((const float*)g.residual)[o];
-          }
-        }
-        const int64_t o = coff + m * g.ldc + n;
-        if (g.c_dtype == SEGCLIP_BF16) ((bf16_t*)g.C)[o] = f2bf(v); else ((float*)g.C)[o] = v;
-      }
-    }
+  const bool full = m0 + BM <= g.M && n0 + BN <= g.N && ((g.ldc | g.ldaux | coff) & 1) == 0;
+  if (g.c_dtype == SEGCLIP_BF16) {
+    if (full) epilogue_mode<bf16_t, true>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+    else epilogue_mode<bf16_t, false>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+  } else {
+    if (full) epilogue_mode<float, true>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+    else epilogue_mode<float, false>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+  }
 }
 
 // C = alpha * sum_s slab[s]  (split-K combine; deterministic order)
@@ -303,11 +295,40 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, in
 
 }  // namespace
 
+bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t kper, int64_t nb,
+                               hipStream_t stream);
+
+static bool aligned16(const segclip_gemm_desc* d) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
+  const int64_t lda = a_ks ? d->sak : d->sam, ldb = b_ks ? d->sbk : d->sbn;
+  const int64_t aes = d->a_dtype == SEGCLIP_F32 ? 4 : 2;
+  bool fast = al(d->A) && al(d->B) && lda % 8 == 0 && ldb % 8 == 0 && (d->bsA1 * aes) % 16 == 0 &&
+              (d->bsA2 * aes) % 16 == 0 && (d->bsB1 * 2) % 16 == 0 && (d->bsB2 * 2) % 16 == 0;
+  fast = fast && (a_ks ? (d->M % 8 == 0 && d->M >= 8) : (d->K % 8 == 0 && d->K >= 8));
+  fast = fast && (b_ks ? (d->N % 8 == 0 && d->N >= 8) : (d->K % 8 == 0 && d->K >= 8));
+  return fast;
+}
+// the LDS-DMA kernel (256x128 tiles) takes the large aligned bf16 x bf16 problems
+static bool want_dma(const segclip_gemm_desc* d) {
+  return d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16 && aligned16(d) && d->K % 32 == 0 && d->K >= 32 &&
+         d->M >= 64 && d->N >= 16;
+}
 static int choose_splits(const segclip_gemm_desc* d) {
   if (d->bias || d->residual || d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact) return 1;
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
-  const int64_t tiles = cdiv(d->M, BM) * cdiv(d->N, BN) * nb;
   const int64_t ksteps = cdiv(d->K, BK);
+  if (want_dma(d)) {
+    // 256-row tiles, long K loops: aim at one full round of the 256 CUs
+    const int64_t bn = d->N > 128 ? 256 : 128;
+    const int64_t tiles = cdiv(d->M, 256) * cdiv(d->N, bn) * nb;
+    if (tiles >= 160 || ksteps < 32) return 1;
+    int64_t s = 256 / tiles;
+    if (s > ksteps / 8) s = ksteps / 8;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+  }
+  const int64_t tiles = cdiv(d->M, BM) * cdiv(d->N, BN) * nb;
   if (tiles >= 384 || ksteps < 16) return 1;
   int64_t s = cdiv(768, tiles);
   if (s > ksteps / 4) s = ksteps / 4;
@@ -329,13 +350,15 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   SEGCLIP_REQUIRE(!b_ks || d->sbn == 1, "gemm_bf16: B needs unit stride along k or n (sbn=%lld sbk=%lld)",
                   (long long)d->sbn, (long long)d->sbk);
   SEGCLIP_REQUIRE(d->b_dtype == SEGCLIP_BF16, "gemm_bf16: B must be bf16");
+  const bool a_f32 = d->a_dtype == SEGCLIP_F32;
   Args g;
   g.A = d->A; g.B = (const bf16_t*)d->B; g.C = d->C; g.bias = d->bias; g.residual = d->residual; g.aux = d->aux;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.lda = a_ks ? d->sak : d->sam; g.ldb = b_ks ? d->sbk : d->sbn;
   g.ldc = d->ldc; g.ldr = d->ldr; g.ldaux = d->ldaux;
   g.nb2 = d->nb2 > 0 ? d->nb2 : 1;
-  g.bsA1 = d->bsA1; g.bsA2 = d->bsA2; g.bsB1 = d->bsB1; g.bsB2 = d->bsB2; g.bsC1 = d->bsC1; g.bsC2 = d->bsC2; g.bsR1 = d->bsR1; g.bsR2 = d->bsR2;
+  g.bsA1 = d->bsA1; g.bsA2 = d->bsA2; g.bsB1 = d->bsB1; g.bsB2 = d->bsB2; g.bsC1 = d->bsC1; g.bsC2 = d->bsC2;
+  g.bsR1 = d->bsR1; g.bsR2 = d->bsR2;
   g.c_dtype = d->c_dtype; g.r_dtype = d->r_dtype; g.act = d->act; g.mul_dact = d->mul_dact; g.alpha = d->alpha;
   g.nbx = (int)cdiv(d->N, BN); g.nby = (int)cdiv(d->M, BM);
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * g.nb2;
@@ -345,14 +368,23 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.kper = g.splits > 1 ? cdiv(cdiv(d->K, BK), g.splits) * BK : d->K;
   if (g.splits > 1) g.splits = (int)cdiv(d->K, g.kper);
   g.slab = (float*)d->ws;
+  g.vec_epi = 0;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
-  const bool a_f32 = d->a_dtype == SEGCLIP_F32;
-#define LAUNCH(AK, BKS, AF) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, AF>), grid, dim3(NT), 0, stream, g)
+  const bool fast = aligned16(d);
+  bool launched = false;
+  if (want_dma(d)) launched = segclip_gemm_bf16_dma_try(d, &g, g.splits, g.kper, nb, stream);
+  if (!launched) {
+#define LAUNCH(AK, BKS, AF)                                                                                         \
+  do {                                                                                                              \
+    if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, AF, true>), grid, dim3(NT), 0, stream, g);              \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, AF, false>), grid, dim3(NT), 0, stream, g);                  \
+  } while (0)
   if (!a_ks && !b_ks) { if (a_f32) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
   else if (!a_ks && b_ks) { if (a_f32) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
   else if (a_ks && b_ks) { if (a_f32) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
   else { if (a_f32) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
 #undef LAUNCH
+  }
   SEGCLIP_CHECK_LAUNCH("gemm_bf16");
   if (g.splits > 1) {
     const int64_t total = nb * d->M * d->N;

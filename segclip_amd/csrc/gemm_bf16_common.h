@@ -1,0 +1,210 @@
+// Shared by the two bf16 GEMM kernels (register-staged gemm_bf16.hip, LDS-DMA gemm_bf16_dma.hip):
+// argument block and the fused epilogue of one wave's 64x64 sub-tile (2x2 MFMA 32x32 accumulators).
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct Args {
+  const void* A; const bf16_t* B; void* C;
+  const float* bias; const void* residual; void* aux;
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
+  int64_t nb2, bsA1, bsA2, bsB1, bsB2, bsC1, bsC2, bsR1, bsR2;
+  int c_dtype, r_dtype, act, mul_dact; float alpha;
+  int nbx, nby;
+  int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
+  int vec_epi;  // host-checked: every C / aux / residual / bias access of a full tile may be a 16-byte vector
+};
+
+
+// ---- epilogue -------------------------------------------------------------------------------
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
+
+template <typename CT> __device__ __forceinline__ float ldc_(const void* p, int64_t o);
+template <> __device__ __forceinline__ float ldc_<bf16_t>(const void* p, int64_t o) { return bf2f(((const bf16_t*)p)[o]); }
+template <> __device__ __forceinline__ float ldc_<float>(const void* p, int64_t o) { return ((const float*)p)[o]; }
+
+// FULL: whole 128x128 tile in range (no per-element bounds checks; bf16 output stored as packed column
+// pairs after a lane^1 exchange: 4-byte stores instead of 2-byte ones).
+template <typename CT, int MODE, bool FULL>
+__device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm, int wn,
+                                         int lane, int64_t coff, int64_t roff) {
+  const int li = lane & 31, lk = lane >> 5;
+  constexpr bool PAIR = FULL && sizeof(CT) == 2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + li;
+      if (!FULL && n >= g.N) continue;
+      const float bv = (MODE != EPI_DACT && g.bias) ? g.bias[n] : 0.f;
+      float val[16], pre[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        float v = g.alpha * acc[i][j][r];
+        pre[r] = 0.f;
+        if (FULL || m < g.M) {
+          if (MODE == EPI_DACT) {
+            v *= apply_act_grad(g.act, ldc_<CT>(g.aux, coff + m * g.ldaux + n));
+          } else {
+            v += bv;
+            if (MODE == EPI_ACT) { pre[r] = v; v = apply_act(g.act, v); }
+            if (g.residual) {
+              const int64_t o = roff + m * g.ldr + n;
+              v += g.r_dtype == SEGCLIP_BF16 ? bf2f(((const bf16_t*)g.residual)[o]) : ((const float*)g.residual)[o];
+            }
+          }
+        }
+        val[r] = v;
+      }
+      if constexpr (PAIR) {
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk + (odd ? 1 : 0);
+          const float recv = __shfl_xor(odd ? val[r] : val[r + 1], 1, 64);
+          const uint32_t w = odd ? pack2bf(recv, val[r + 1]) : pack2bf(val[r], recv);
+          *reinterpret_cast<uint32_t*>((bf16_t*)g.C + coff + m * g.ldc + (n & ~(int64_t)1)) = w;
+          if (MODE == EPI_ACT && g.aux) {
+            const float rp = __shfl_xor(odd ? pre[r] : pre[r + 1], 1, 64);
+            const uint32_t wp = odd ? pack2bf(rp, pre[r + 1]) : pack2bf(pre[r], rp);
+            *reinterpret_cast<uint32_t*>((bf16_t*)g.aux + coff + m * g.ldaux + (n & ~(int64_t)1)) = wp;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (!FULL && m >= g.M) continue;
+          if (sizeof(CT) == 2) ((bf16_t*)g.C)[coff + m * g.ldc + n] = f2bf(val[r]);
+          else ((float*)g.C)[coff + m * g.ldc + n] = val[r];
+          if (MODE == EPI_ACT && g.aux) {
+            if (sizeof(CT) == 2) ((bf16_t*)g.aux)[coff + m * g.ldaux + n] = f2bf(pre[r]);
+            else ((float*)g.aux)[coff + m * g.ldaux + n] = pre[r];
+          }
+        }
+      }
+    }
+}
+
+template <typename CT, bool FULL>
+__device__ __forceinline__ void epilogue_mode(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm,
+                                              int wn, int lane, int64_t coff, int64_t roff) {
+  if (g.mul_dact) epilogue<CT, EPI_DACT, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+  else if (g.act != SEGCLIP_ACT_NONE) epilogue<CT, EPI_ACT, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+  else epilogue<CT, EPI_PLAIN, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+}
+
+
+// ---- LDS-staged epilogue of one wave's 64x64 sub-tile (full tiles, 16-byte aligned operands) ---------
+// Phase 1: the wave parks its alpha-scaled fp32 accumulators in a private [64][68] fp32 LDS patch.
+// Phase 2: each lane re-reads 8 (bf16 out) / 4 (fp32 out) consecutive columns of a row, applies
+// bias / activation / act' / residual with 16-byte loads, and writes one 16-byte chunk: every global
+// access of the epilogue is a full, coalesced line segment (the per-element form wrote 2-4 bytes/lane).
+constexpr int EPI_PITCH = 68;
+constexpr int EPI_WAVE_BYTES = 64 * EPI_PITCH * 4;  // 17408
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(v[j] << 16); f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u); }
+}
+
+template <typename CT, int MODE>
+__device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
+                                             int lane, int64_t coff, int64_t roff) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();
+  constexpr int W = sizeof(CT) == 2 ? 8 : 4;      // columns per lane
+  constexpr int LPR = 64 / W;                      // lanes per row
+  constexpr int RPI = 64 / LPR;                    // rows per iteration
+  const int cl = lane % LPR, rl = lane / LPR;
+  const int64_t n = nw + cl * W;
+  float bias[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) bias[c] = 0.f;
+  if (MODE != EPI_DACT && g.bias) {
+#pragma unroll
+    for (int c = 0; c < W; c += 4) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n + c);
+      bias[c] = b[0]; bias[c + 1] = b[1]; bias[c + 2] = b[2]; bias[c + 3] = b[3];
+    }
+  }
+#pragma unroll 1
+  for (int it = 0; it < 64 / RPI; ++it) {
+    const int row = it * RPI + rl;
+    const int64_t m = mw + row;
+    float v[W];
+#pragma unroll
+    for (int c = 0; c < W; c += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
+      v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
+    }
+    if (MODE == EPI_DACT) {
+      float u[W];
+      if (sizeof(CT) == 2) unpack8(*reinterpret_cast<const u32x4*>((const bf16_t*)g.aux + coff + m * g.ldaux + n), u);
+      else { const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)g.aux + coff + m * g.ldaux + n);
+             u[0] = a[0]; u[1] = a[1]; u[2] = a[2]; u[3] = a[3]; }
+#pragma unroll
+      for (int c = 0; c < W; ++c) v[c] *= apply_act_grad(g.act, u[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < W; ++c) v[c] += bias[c];
+      if (MODE == EPI_ACT) {
+        if (g.aux) {
+          if (sizeof(CT) == 2) {
+            u32x4 p; for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+            *reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n) = p;
+          } else {
+            *reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] = apply_act(g.act, v[c]);
+      }
+      if (g.residual) {
+        const int64_t o = roff + m * g.ldr + n;
+        if (g.r_dtype == SEGCLIP_BF16) {
+          float rr[8];
+          if (W == 8) { unpack8(*reinterpret_cast<const u32x4*>((const bf16_t*)g.residual + o), rr); }
+          else { const u32x2 q = *reinterpret_cast<const u32x2*>((const bf16_t*)g.residual + o);
+                 rr[0] = __uint_as_float(q[0] << 16); rr[1] = __uint_as_float(q[0] & 0xffff0000u);
+                 rr[2] = __uint_as_float(q[1] << 16); rr[3] = __uint_as_float(q[1] & 0xffff0000u); }
+#pragma unroll
+          for (int c = 0; c < W; ++c) v[c] += rr[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < W; c += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)g.residual + o + c);
+            v[c] += a[0]; v[c + 1] += a[1]; v[c + 2] += a[2]; v[c + 3] += a[3];
+          }
+        }
+      }
+    }
+    if (sizeof(CT) == 2) {
+      u32x4 p;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+      *reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n) = p;
+    } else {
+      *reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+template <typename CT>
+__device__ __forceinline__ void epilogue_lds_mode(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
+                                                  int64_t nw, int lane, int64_t coff, int64_t roff) {
+  if (g.mul_dact) epilogue_lds<CT, EPI_DACT>(g, acc, t, mw, nw, lane, coff, roff);
+  else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds<CT, EPI_ACT>(g, acc, t, mw, nw, lane, coff, roff);
+  else epilogue_lds<CT, EPI_PLAIN>(g, acc, t, mw, nw, lane, coff, roff);
+}
+
+}  // namespace

@@ -1,0 +1,311 @@
+// bf16 MFMA GEMM, LDS-DMA pipeline (the fast path for the large, aligned shapes of the training step).
+// C[z](m,n) = epi(alpha * sum_k A(m,k) * B(n,k)),  A and B bf16, each k-contiguous or k-strided.
+//
+// Tile 256 x BN x 32 (BN = 256 or 128), 512 threads = 8 waves (two per SIMD):
+//   BN=256: waves 2(m) x 4(n), each 128x64 = 4x2 MFMA 32x32x16 accumulators (128 VGPRs)
+//   BN=128: waves 4(m) x 2(n), each  64x64 = 2x2
+// The 256x256 tile halves the operand bytes per MFMA of the 256x128 one (the L2 -> LDS path, not the
+// matrix pipe, was the limiter of the smaller tile); BN=128 is kept for N < 256*k shapes (tile count).
+// Operand slices go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR
+// round trip) into a 4-stage ring of 32-deep K slices (4 x 32 KiB): the DMA of slice t+3 is issued right
+// after the barrier that publishes slice t and stays in flight under three slices of MFMAs.  Waits are
+// counted (s_waitcnt vmcnt(2n): only slice t's n DMAs must have landed), barriers are raw s_barrier.
+// An LDS-DMA write is lane-linear (wave base + lane*16), so the bank-conflict swizzle is applied to the
+// per-lane SOURCE address and again on the fragment read:
+//   k-contiguous operand: [rows][32 k] 64-B rows, 16-B chunk ^ ((row>>2)&3)  -> conflict-free ds_read_b128
+//   k-strided operand   : [32 k][rows] rows*2-B k-rows, 16-B chunk ^ ((k&3)<<2) -> conflict-free
+//                         ds_read_b64_tr_b16 (the 4 k-rows of a transpose read land in 4 bank quadrants)
+// MFMA operand fragments of both 16-deep chunks of a slice are requested before its first MFMA.
+// Full tiles leave through the LDS-staged coalesced epilogue (gemm_bf16_common.h).
+// Rows beyond M / N are clamped to valid addresses (their products are never stored); K must be a
+// multiple of 32 (the host falls back to the register-staged kernel otherwise).
+#include "gemm_bf16_common.h"
+
+namespace {
+
+constexpr int BM = 256, BK = 32, NT = 512, STAGES = 4;
+constexpr int SZA = BM * BK * 2;  // 16384
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ void dma16(const bf16_t* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// k-contiguous operand with ROWS rows: X(row,k) = X[row*ld + k]; [ROWS][64 B]; ROWS/128 pieces per wave.
+template <int ROWS>
+__device__ __forceinline__ void issue_direct(const bf16_t* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows,
+                                             int64_t k0, char* lds, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 128;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int idx = wave * PER_WAVE + i;        // 1-KiB piece = 16 rows of 64 B
+    const int row = idx * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    int64_t r = row0 + row;
+    r = r < nrows ? r : nrows - 1;
+    dma16(X + r * ld + k0 + chunk * 8, lds + idx * 1024);
+  }
+}
+// k-strided operand with ROWS rows: X(row,k) = X[k*ld + row]; LDS image [32 k][ROWS], k-row = ROWS*2 bytes.
+template <int ROWS>
+__device__ __forceinline__ void issue_ks(const bf16_t* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows,
+                                         int64_t k0, char* lds, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 128;          // 32 k-rows * ROWS*2 B / 1 KiB / 8 waves
+  constexpr int CHUNKS = ROWS / 8;              // 16-B chunks per k-row
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int idx = wave * PER_WAVE + i;
+    const int krow = idx * (512 / ROWS) + lane / CHUNKS;
+    const int chunk = (lane % CHUNKS) ^ ((krow & 3) << 2);
+    int64_t r = row0 + chunk * 8;
+    r = r + 8 <= nrows ? r : nrows - 8;
+    dma16(X + (k0 + krow) * ld + r, lds + idx * 1024);
+  }
+}
+
+// lane l -> row rbase + (l&31), k = kc*16 + 8*(l>>5) .. +7
+__device__ __forceinline__ bf16x8_t frag_direct(const char* lds, int rbase, int kc, int lane) {
+  const int r = rbase + (lane & 31);
+  const int c = kc * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8_t*>(lds + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+}
+template <int ROWS>
+__device__ __forceinline__ bf16x8_t frag_ks(const char* lds, int rbase, int kc, int lane) {
+  const int g4 = lane >> 4, q = lane & 15;
+  const int krow = kc * 16 + 8 * (g4 >> 1) + (q >> 2);
+  const int col = rbase + 16 * (g4 & 1) + 4 * (q & 3);
+  const char* p = lds + krow * (ROWS * 2) + ((((col >> 3) ^ ((krow & 3) << 2))) << 4) + ((col & 7) << 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * (ROWS * 2)));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <bool A_KS, bool B_KS, int BN>
+__global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
+  constexpr int SZB = BN * BK * 2;
+  constexpr int SZS = SZA + SZB;
+  constexpr int TM = BN == 256 ? 4 : 2;               // 32-row MFMA tiles per wave along m
+  constexpr int WROWS = TM * 32;                       // rows per wave
+  constexpr int NDMA = BM / 128 + BN / 128;            // DMA instructions per wave per slice
+  constexpr int LDS_BYTES = STAGES * SZS > 8 * EPI_WAVE_BYTES ? STAGES * SZS : 8 * EPI_WAVE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1);
+  const int wn = BN == 256 ? (wave & 3) : (wave & 1);
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t n0 = (int64_t)(wg % g.nbx) * BN, m0 = (int64_t)(wg / g.nbx) * BM;
+  const int64_t z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.bsA1 + z2 * g.bsA2;
+  const bf16_t* B = g.B + z1 * g.bsB1 + z2 * g.bsB2;
+  const int64_t coff = z1 * g.bsC1 + z2 * g.bsC2;
+  const int64_t roff = z1 * g.bsR1 + z2 * g.bsR2;
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t kbeg = (int64_t)blockIdx.y * g.kper;
+  const int64_t kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+  const int nk = (int)((kend - kbeg) / BK);
+
+  auto issue = [&](int t) {
+    char* la = smem + (t & 3) * SZS;
+    char* lb = la + SZA;
+    const int64_t k0 = kbeg + (int64_t)t * BK;
+    if constexpr (A_KS) issue_ks<BM>(A, g.lda, m0, g.M, k0, la, wave, lane);
+    else issue_direct<BM>(A, g.lda, m0, g.M, k0, la, wave, lane);
+    if constexpr (B_KS) issue_ks<BN>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
+    else issue_direct<BN>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
+  };
+
+  // ---- main loop: the two waves of every SIMD run half a slice out of phase (ping-pong) -------------
+  // Waves 0-3 (group 0) and 4-7 (group 1) share the four SIMDs pairwise.  Each 32-deep slice takes two
+  // barrier-delimited intervals; in every interval one group issues its DMA share + all its ds_reads for
+  // a slice while the other group runs that SIMD's matrix pipe with 4*TM MFMAs, so LDS traffic and MFMAs
+  // of a SIMD always overlap instead of alternating in lockstep.
+  //   group 0, slice t:  [issue DMA t+3, read frags t] B1 [MFMA t, wait DMA t+1] B2
+  //   group 1, slice t:  [MFMA t-1]                   B1 [issue DMA t+3, read frags t, wait DMA t+1] B2
+  bf16x8_t fa[2][TM], fb[2][2];
+  auto ldfrags = [&](int t) {
+    const char* la = smem + (t & 3) * SZS;
+    const char* lb = la + SZA;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[kc][i] = A_KS ? frag_ks<BM>(la, wm * WROWS + i * 32, kc, lane) : frag_direct(la, wm * WROWS + i * 32, kc, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[kc][j] = B_KS ? frag_ks<BN>(lb, wn * 64 + j * 32, kc, lane) : frag_direct(lb, wn * 64 + j * 32, kc, lane);
+    }
+  };
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc][i], fb[kc][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto wait_slice = [&](int t) {  // this wave's DMAs of slice t have landed (younger slices may be in flight)
+    if (t >= nk) return;
+    if (t + 2 < nk) wait_vm<2 * NDMA>();
+    else if (t + 1 < nk) wait_vm<NDMA>();
+    else wait_vm<0>();
+  };
+#define BAR()                           \
+  do {                                  \
+    __builtin_amdgcn_sched_barrier(0);  \
+    __builtin_amdgcn_s_barrier();       \
+    __builtin_amdgcn_sched_barrier(0);  \
+  } while (0)
+
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  wait_slice(0);
+  BAR();
+  if (wave < 4) {
+    for (int t = 0; t < nk; ++t) {
+      if (t + 3 < nk) issue(t + 3);
+      ldfrags(t);
+      BAR();
+      mfmas();
+      wait_slice(t + 1);
+      BAR();
+    }
+  } else {
+    for (int t = 0; t < nk; ++t) {
+      if (t > 0) mfmas();
+      BAR();
+      if (t + 3 < nk) issue(t + 3);
+      ldfrags(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot t may be refilled after the next barrier
+      wait_slice(t + 1);
+      BAR();
+    }
+    mfmas();
+  }
+#undef BAR
+
+  const int64_t mw = m0 + wm * WROWS;  // this wave's WROWS x 64 sub-tile
+  const int64_t nw = n0 + wn * 64;
+  if (g.splits > 1) {
+    const int li = lane & 31, lk = lane >> 5;
+    float* slab = g.slab + ((int64_t)blockIdx.y * gridDim.z + z) * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t n = nw + j * 32 + li;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (m < g.M) slab[m * g.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  const bool full = m0 + BM <= g.M && n0 + BN <= g.N;  // uniform over the workgroup
+  const bool vec = full && g.vec_epi;
+  if (vec) __syncthreads();  // every wave is done with the operand ring: the LDS is reused as 8 private patches
+  float* t = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+#define RUN_EPI(SUB, MROW)                                                                              \
+  do {                                                                                                  \
+    if (vec) {                                                                                          \
+      if (g.c_dtype == SEGCLIP_BF16) epilogue_lds_mode<bf16_t>(g, SUB, t, MROW, nw, lane, coff, roff);  \
+      else epilogue_lds_mode<float>(g, SUB, t, MROW, nw, lane, coff, roff);                             \
+    } else {                                                                                            \
+      if (g.c_dtype == SEGCLIP_BF16) epilogue_mode<bf16_t, false>(g, SUB, MROW, nw, 0, 0, lane, coff, roff); \
+      else epilogue_mode<float, false>(g, SUB, MROW, nw, 0, 0, lane, coff, roff);                       \
+    }                                                                                                   \
+  } while (0)
+  if constexpr (TM == 2) {
+    RUN_EPI(acc, mw);
+  } else {
+    f32x16 lo[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+    RUN_EPI(lo, mw);
+    __builtin_amdgcn_wave_barrier();
+    f32x16 hi[2][2] = {{acc[2][0], acc[2][1]}, {acc[3][0], acc[3][1]}};
+    RUN_EPI(hi, mw + 64);
+  }
+#undef RUN_EPI
+}
+
+}  // namespace
+
+// tile-count heuristic: the 256x256 tile unless it leaves the 256 CUs badly quantised and 256x128 does not
+static int pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits) {
+  if (d->N <= 128) return 128;
+  auto eff = [&](int bn) {
+    const double tiles = (double)cdiv(d->M, BM) * cdiv(d->N, bn) * nbatch_splits;
+    const double rounds = tiles / 256.0;
+    const double q = rounds / (double)(int64_t)(rounds + 0.999999);  // quantisation efficiency
+    const double pad = (double)d->N / (cdiv(d->N, bn) * bn);
+    return q * pad * (bn == 256 ? 1.0 : 0.72);                       // 256x128 runs at ~0.72 of the 256x256 rate
+  };
+  return eff(256) >= eff(128) ? 256 : 128;
+}
+
+// Launch the LDS-DMA kernel.  `args_` is prepared by the caller (gemm_bf16.hip); returns false when the shape
+// does not meet this kernel's preconditions (the caller then uses the register-staged kernel).
+bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t kper, int64_t nb,
+                               hipStream_t stream) {
+  Args g = *reinterpret_cast<const Args*>(args_);
+  const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
+  if (d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16) return false;
+  if (d->K % BK != 0 || kper % BK != 0 || d->K < BK) return false;
+  if (a_ks && (d->M % 8 != 0 || d->M < 8)) return false;
+  if (b_ks && (d->N % 8 != 0 || d->N < 8)) return false;
+  if (d->M < 64 || d->N < 16) return false;  // tiny problems: the 128x128 kernel wastes less
+  const int bn = pick_bn(d, nb * splits);
+  g.nbx = (int)cdiv(d->N, bn);
+  g.nby = (int)cdiv(d->M, BM);
+  g.splits = splits;
+  g.kper = kper;
+  {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int64_t ce = d->c_dtype == SEGCLIP_BF16 ? 8 : 4, re = d->r_dtype == SEGCLIP_BF16 ? 8 : 4;
+    g.vec_epi = al(d->C) && al(d->aux) && al(d->residual) && al(d->bias) && d->ldc % ce == 0 &&
+                (!d->aux || d->ldaux % ce == 0) && (!d->residual || d->ldr % re == 0) && d->bsC1 % ce == 0 &&
+                d->bsC2 % ce == 0 && (!d->residual || (d->bsR1 % re == 0 && d->bsR2 % re == 0));
+  }
+  dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
+#define GO(AK, BKS)                                                                                          \
+  do {                                                                                                       \
+    if (bn == 256) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256>), grid, dim3(NT), 0, stream, g);   \
+    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128>), grid, dim3(NT), 0, stream, g);             \
+  } while (0)
+  if (!a_ks && !b_ks) GO(false, false);
+  else if (!a_ks && b_ks) GO(false, true);
+  else if (a_ks && b_ks) GO(true, true);
+  else GO(true, false);
+#undef GO
+  return true;
+}

@@ -154,15 +154,23 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
   }
 }
 
-// out[c] = sum_b part[b][c]   (part has `nb` rows of `width` floats)
-__global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                 int nb, int cols) {
-  // width = 2*cols; thread handles one of the 2*cols columns
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * cols) return;
+// out[c] = sum_b part[b][c] over the 2*cols columns (dgamma | dbeta); block = 64 columns x 16 row lanes
+__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                          float* __restrict__ out1, int nb, int cols) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * 2 * cols + c];
-  if (c < cols) out0[c] = s; else out1[c - cols] = s;
+  if (c < 2 * cols)
+    for (int b = rl; b < nb; b += 16) s += part[(int64_t)b * 2 * cols + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < 2 * cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    if (c < cols) out0[c] = t; else out1[c - cols] = t;
+  }
 }
 
 int ln_blocks(int64_t rows) {
@@ -211,7 +219,7 @@ extern "C" int segclip_layernorm_bwd(const void* dy, const void* x, const float*
   }
 #undef LNB
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)cdiv(2 * cols, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)ws, dgamma, dbeta, nb, (int)cols);
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd_reduce");
   return 0;

@@ -73,20 +73,42 @@ __global__ void reduce_sum_kernel(const float* x, float* out, int64_t n, float s
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
-constexpr int CS_ROWS = 128;  // rows per chunk
-__global__ void colsum_partial_kernel(const void* __restrict__ X, float* __restrict__ part, int64_t M, int64_t N,
-                                      int64_t ld, int dt) {
-  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-  if (c >= N) return;
-  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
-  float s0 = 0.f, s1 = 0.f;
-  const bool two = c + 1 < N;
-  for (int64_t r = r0; r < r1; ++r) {
-    s0 += ldx(X, dt, r * ld + c);
-    if (two) s1 += ldx(X, dt, r * ld + c + 1);
+// stage 1: block = 64 column-quads x 4 row lanes over one row chunk -> part[chunk][N]; stage 2 sums <=128 chunks.
+constexpr int CS_MAXCHUNK = 128;
+__device__ __forceinline__ f32x4 ld4x(const void* X, int dt, int64_t idx, bool vec, int nvalid) {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if (dt == SEGCLIP_F32) r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + idx);
+    else {
+      const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(X) + idx);
+      r[0] = __uint_as_float(t[0] << 16); r[1] = __uint_as_float(t[0] & 0xffff0000u);
+      r[2] = __uint_as_float(t[1] << 16); r[3] = __uint_as_float(t[1] & 0xffff0000u);
+    }
+  } else {
+    for (int j = 0; j < nvalid; ++j) r[j] = ldx(X, dt, idx + j);
   }
-  part[(int64_t)blockIdx.y * N + c] = s0;
-  if (two) part[(int64_t)blockIdx.y * N + c + 1] = s1;
+  return r;
+}
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ X, float* __restrict__ part,
+                                                             int64_t M, int64_t N, int64_t ld, int dt, int64_t rows_per) {
+  __shared__ f32x4 red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + cl) * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    const int nvalid = (int)(N - c < 4 ? N - c : 4);
+    const int esz = dt == SEGCLIP_F32 ? 4 : 2;
+    const bool vec = nvalid == 4 && (ld * esz) % (4 * esz) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(X) + c * esz) % (4 * esz)) == 0;
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += ld4x(X, dt, r * ld + c, vec, nvalid);
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const f32x4 t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    for (int j = 0; j < 4 && c + j < N; ++j) part[(int64_t)blockIdx.y * N + c + j] = t[j];
+  }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t nchunk, int64_t N) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +116,10 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
   float s = 0.f;
   for (int64_t k = 0; k < nchunk; ++k) s += part[k * N + c];
   out[c] = s;
+}
+static inline int64_t colsum_chunks(int64_t M) {
+  int64_t c = cdiv(M, 256);
+  return c < 1 ? 1 : (c > CS_MAXCHUNK ? CS_MAXCHUNK : c);
 }
 
 // ---------------------------------------------------------------- vision front end
@@ -429,16 +455,15 @@ extern "C" int segclip_reduce_sum(const float* x, float* out, int64_t n, float s
   SEGCLIP_CHECK_LAUNCH("reduce_sum");
   return 0;
 }
-extern "C" size_t segclip_colsum_ws_bytes(int64_t M, int64_t N) { return (size_t)cdiv(M, CS_ROWS) * N * sizeof(float); }
+extern "C" size_t segclip_colsum_ws_bytes(int64_t M, int64_t N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
 extern "C" int segclip_colsum(const void* X, float* out, void* ws, int64_t M, int64_t N, int64_t ld, int dt, void* stream) {
   SEGCLIP_REQUIRE(ws != nullptr, "colsum: workspace required");
   if (N == 0) return 0;
-  const int64_t nchunk = cdiv(M, CS_ROWS);
-  if (nchunk > 0) {
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cdiv(N, 2), 128), (unsigned)nchunk), dim3(128), 0, ST, X,
-                       (float*)ws, M, N, ld, dt);
-    SEGCLIP_CHECK_LAUNCH("colsum_partial");
-  }
+  const int64_t nchunk = colsum_chunks(M);
+  const int64_t rows_per = cdiv(M > 0 ? M : 1, nchunk);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(N, 256), (unsigned)nchunk), dim3(256), 0, ST, X, (float*)ws,
+                     M, N, ld, dt, rows_per);
+  SEGCLIP_CHECK_LAUNCH("colsum_partial");
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, ST, (const float*)ws, out, nchunk, N);
   SEGCLIP_CHECK_LAUNCH("colsum_final");
   return 0;

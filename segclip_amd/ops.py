@@ -20,6 +20,25 @@ from . import _lib as L
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = L.ACT_NONE, L.ACT_QUICK_GELU, L.ACT_GELU_ERF
 
 
+class _GemmProfile:
+    """Optional per-launch timing of the dominant (GEMM) kernel with HIP events on the launch stream
+    (bench.py's roofline leg).  Off by default; adds two event records per launch when enabled."""
+    enabled = False
+    records = []  # (start_event, end_event, flops, is_bf16)
+
+    @classmethod
+    def start(cls):
+        cls.enabled, cls.records = True, []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = [(s.elapsed_time(e) * 1e-3, f, b) for s, e, f, b in cls.records]
+        cls.records = []
+        return out
+
+
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -64,6 +83,13 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     if nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = L.ptr(ws), nbytes
+    if _GemmProfile.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.segclip_gemm(C.byref(d), L.stream()), "gemm")
+        e1.record()
+        _GemmProfile.records.append((e0, e1, 2.0 * M * N * K * nb1 * nb2, B.dtype == torch.bfloat16))
+        return Cc
     L.check(lib.segclip_gemm(C.byref(d), L.stream()), "gemm")
     return Cc
 
