@@ -84,6 +84,9 @@ int segclip_gemm(const segclip_gemm_desc* d, void* stream);
  * LayerNorm over the last axis (fp32 statistics).  modules/module_clip_util.py:126-132,
  * modules/module_seg_vit.py:150-156 (eps 1e-5), modules/modeling.py:152 (eps 1e-6).
  * bwd: dx = LN'(dy) (+ dres if given);  dgamma/dbeta (fp32, [cols]) are fully reduced.
+ *      dx_bf16 (optional): a bf16 copy of dx for the GEMMs that consume it next;
+ *      dres_colsum (optional, needs dres): column sums of dres = the bias gradient of the Linear whose
+ *      output gradient dres is (fused here because this kernel streams dres anyway).
  * ws: segclip_layernorm_bwd_ws_bytes(rows, cols) bytes of scratch.
  * ------------------------------------------------------------------------------------------ */
 int segclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
@@ -91,9 +94,9 @@ int segclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, 
                           void* stream);
 size_t segclip_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols);
 int segclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                          const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                          void* ws, int64_t rows, int64_t cols, int dy_dtype, int x_dtype, int dx_dtype,
-                          void* stream);
+                          const float* rstd, const void* dres, void* dx, void* dx_bf16, float* dgamma,
+                          float* dbeta, float* dres_colsum, void* ws, int64_t rows, int64_t cols, int dy_dtype,
+                          int x_dtype, int dx_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention core  O = softmax(scale * Q K^T [+ causal mask]) V,  head_dim <= 64.

@@ -311,7 +311,7 @@ static bool aligned16(const segclip_gemm_desc* d) {
 }
 // the LDS-DMA kernel (256x128 tiles) takes the large aligned bf16 x bf16 problems
 static bool want_dma(const segclip_gemm_desc* d) {
-  return d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16 && aligned16(d) && d->K % 32 == 0 && d->K >= 32 &&
+  return d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16 && aligned16(d) && d->K % 64 == 0 && d->K >= 64 &&
          d->M >= 64 && d->N >= 16;
 }
 static int choose_splits(const segclip_gemm_desc* d) {

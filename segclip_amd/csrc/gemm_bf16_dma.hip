@@ -1,30 +1,30 @@
 // bf16 MFMA GEMM, LDS-DMA pipeline (the fast path for the large, aligned shapes of the training step).
 // C[z](m,n) = epi(alpha * sum_k A(m,k) * B(n,k)),  A and B bf16, each k-contiguous or k-strided.
 //
-// Tile 256 x BN x 32 (BN = 256 or 128), 512 threads = 8 waves (two per SIMD):
+// Tile 256 x BN x 64 (BN = 256 or 128), 512 threads = 8 waves (two per SIMD):
 //   BN=256: waves 2(m) x 4(n), each 128x64 = 4x2 MFMA 32x32x16 accumulators (128 VGPRs)
 //   BN=128: waves 4(m) x 2(n), each  64x64 = 2x2
-// The 256x256 tile halves the operand bytes per MFMA of the 256x128 one (the L2 -> LDS path, not the
-// matrix pipe, was the limiter of the smaller tile); BN=128 is kept for N < 256*k shapes (tile count).
-// Operand slices go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR
-// round trip) into a 4-stage ring of 32-deep K slices (4 x 32 KiB): the DMA of slice t+3 is issued right
-// after the barrier that publishes slice t and stays in flight under three slices of MFMAs.  Waits are
-// counted (s_waitcnt vmcnt(2n): only slice t's n DMAs must have landed), barriers are raw s_barrier.
+// Operand tiles go L2 -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR round
+// trip) into a double buffer (2 x 64 KiB): the DMA of K-tile t+1 is issued right after the barrier that
+// publishes tile t and lands under tile t's MFMAs.  Measured on MI355X (tools/ubench/dma_bw.hip): an
+// LDS-DMA stream of >=128-byte row pieces sustains ~84 GB/s per CU (21 TB/s chip) from L2, the same
+// stream in 64-byte pieces only 40 GB/s - hence BK = 64 (128-byte rows of a k-contiguous operand) and the
+// 256x256 tile (64 KiB per 2048 MFMA-cycles keeps the DMA engine at ~75 % while the matrix pipe is full).
 // An LDS-DMA write is lane-linear (wave base + lane*16), so the bank-conflict swizzle is applied to the
 // per-lane SOURCE address and again on the fragment read:
-//   k-contiguous operand: [rows][32 k] 64-B rows, 16-B chunk ^ ((row>>2)&3)  -> conflict-free ds_read_b128
-//   k-strided operand   : [32 k][rows] rows*2-B k-rows, 16-B chunk ^ ((k&3)<<2) -> conflict-free
+//   k-contiguous operand: [rows][64 k] 128-B rows, 16-B chunk ^ ((row>>1)&7)  -> conflict-free ds_read_b128
+//   k-strided operand   : [64 k][rows] rows*2-B k-rows, 16-B chunk ^ ((k&3)<<2) -> conflict-free
 //                         ds_read_b64_tr_b16 (the 4 k-rows of a transpose read land in 4 bank quadrants)
-// MFMA operand fragments of both 16-deep chunks of a slice are requested before its first MFMA.
+// MFMA operand fragments are register double-buffered (chunk kc+1 is requested before the MFMAs of kc).
 // Full tiles leave through the LDS-staged coalesced epilogue (gemm_bf16_common.h).
 // Rows beyond M / N are clamped to valid addresses (their products are never stored); K must be a
-// multiple of 32 (the host falls back to the register-staged kernel otherwise).
+// multiple of 64 (the host falls back to the register-staged kernel otherwise).
 #include "gemm_bf16_common.h"
 
 namespace {
 
-constexpr int BM = 256, BK = 32, NT = 512, STAGES = 4;
-constexpr int SZA = BM * BK * 2;  // 16384
+constexpr int BM = 256, BK = 64, NT = 512, STAGES = 2;
+constexpr int SZA = BM * BK * 2;  // 32768
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -34,26 +34,26 @@ __device__ __forceinline__ void dma16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-// k-contiguous operand with ROWS rows: X(row,k) = X[row*ld + k]; [ROWS][64 B]; ROWS/128 pieces per wave.
+// k-contiguous operand with ROWS rows: X(row,k) = X[row*ld + k]; [ROWS][128 B]; ROWS/64 pieces per wave.
 template <int ROWS>
 __device__ __forceinline__ void issue_direct(const bf16_t* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows,
                                              int64_t k0, char* lds, int wave, int lane) {
-  constexpr int PER_WAVE = ROWS / 128;
+  constexpr int PER_WAVE = ROWS / 64;
 #pragma unroll
   for (int i = 0; i < PER_WAVE; ++i) {
-    const int idx = wave * PER_WAVE + i;        // 1-KiB piece = 16 rows of 64 B
-    const int row = idx * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int idx = wave * PER_WAVE + i;        // 1-KiB piece = 8 rows of 128 B
+    const int row = idx * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     int64_t r = row0 + row;
     r = r < nrows ? r : nrows - 1;
     dma16(X + r * ld + k0 + chunk * 8, lds + idx * 1024);
   }
 }
-// k-strided operand with ROWS rows: X(row,k) = X[k*ld + row]; LDS image [32 k][ROWS], k-row = ROWS*2 bytes.
+// k-strided operand with ROWS rows: X(row,k) = X[k*ld + row]; LDS image [64 k][ROWS], k-row = ROWS*2 bytes.
 template <int ROWS>
 __device__ __forceinline__ void issue_ks(const bf16_t* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows,
                                          int64_t k0, char* lds, int wave, int lane) {
-  constexpr int PER_WAVE = ROWS / 128;          // 32 k-rows * ROWS*2 B / 1 KiB / 8 waves
+  constexpr int PER_WAVE = ROWS / 64;           // 64 k-rows * ROWS*2 B / 1 KiB / 8 waves
   constexpr int CHUNKS = ROWS / 8;              // 16-B chunks per k-row
 #pragma unroll
   for (int i = 0; i < PER_WAVE; ++i) {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void issue_ks(const bf16_t* __restrict__ X, int64_t l
 __device__ __forceinline__ bf16x8_t frag_direct(const char* lds, int rbase, int kc, int lane) {
   const int r = rbase + (lane & 31);
   const int c = kc * 2 + (lane >> 5);
-  return *reinterpret_cast<const bf16x8_t*>(lds + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+  return *reinterpret_cast<const bf16x8_t*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
 }
 template <int ROWS>
 __device__ __forceinline__ bf16x8_t frag_ks(const char* lds, int rbase, int kc, int lane) {
@@ -101,7 +101,6 @@ __global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
   constexpr int SZS = SZA + SZB;
   constexpr int TM = BN == 256 ? 4 : 2;               // 32-row MFMA tiles per wave along m
   constexpr int WROWS = TM * 32;                       // rows per wave
-  constexpr int NDMA = BM / 128 + BN / 128;            // DMA instructions per wave per slice
   constexpr int LDS_BYTES = STAGES * SZS > 8 * EPI_WAVE_BYTES ? STAGES * SZS : 8 * EPI_WAVE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
   const int nk = (int)((kend - kbeg) / BK);
 
   auto issue = [&](int t) {
-    char* la = smem + (t & 3) * SZS;
+    char* la = smem + (t & 1) * SZS;
     char* lb = la + SZA;
     const int64_t k0 = kbeg + (int64_t)t * BK;
     if constexpr (A_KS) issue_ks<BM>(A, g.lda, m0, g.M, k0, la, wave, lane);
@@ -140,78 +139,37 @@ __global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
     else issue_direct<BN>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
   };
 
-  // ---- main loop: the two waves of every SIMD run half a slice out of phase (ping-pong) -------------
-  // Waves 0-3 (group 0) and 4-7 (group 1) share the four SIMDs pairwise.  Each 32-deep slice takes two
-  // barrier-delimited intervals; in every interval one group issues its DMA share + all its ds_reads for
-  // a slice while the other group runs that SIMD's matrix pipe with 4*TM MFMAs, so LDS traffic and MFMAs
-  // of a SIMD always overlap instead of alternating in lockstep.
-  //   group 0, slice t:  [issue DMA t+3, read frags t] B1 [MFMA t, wait DMA t+1] B2
-  //   group 1, slice t:  [MFMA t-1]                   B1 [issue DMA t+3, read frags t, wait DMA t+1] B2
-  bf16x8_t fa[2][TM], fb[2][2];
-  auto ldfrags = [&](int t) {
-    const char* la = smem + (t & 3) * SZS;
+  issue(0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t has landed
+    __builtin_amdgcn_s_barrier();                       // ... and everybody else's; buffer (t+1)&1 is free
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) issue(t + 1);
+    const char* la = smem + (t & 1) * SZS;
     const char* lb = la + SZA;
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
+    // fragments of k16-chunk kc+1 are requested before the MFMAs of chunk kc (register double buffer)
+    bf16x8_t fa[2][TM], fb[2][2];
+    auto ldfrag = [&](int kc, bf16x8_t (&a)[TM], bf16x8_t (&b)[2]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa[kc][i] = A_KS ? frag_ks<BM>(la, wm * WROWS + i * 32, kc, lane) : frag_direct(la, wm * WROWS + i * 32, kc, lane);
+        a[i] = A_KS ? frag_ks<BM>(la, wm * WROWS + i * 32, kc, lane) : frag_direct(la, wm * WROWS + i * 32, kc, lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        fb[kc][j] = B_KS ? frag_ks<BN>(lb, wn * 64 + j * 32, kc, lane) : frag_direct(lb, wn * 64 + j * 32, kc, lane);
-    }
-  };
-  auto mfmas = [&]() {
-    __builtin_amdgcn_s_setprio(1);
+        b[j] = B_KS ? frag_ks<BN>(lb, wn * 64 + j * 32, kc, lane) : frag_direct(lb, wn * 64 + j * 32, kc, lane);
+    };
+    ldfrag(0, fa[0], fb[0]);
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
+    for (int kc = 0; kc < 4; ++kc) {
+      if (kc < 3) ldfrag(kc + 1, fa[(kc + 1) & 1], fb[(kc + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (else hipcc re-serialises it)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc][i], fb[kc][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto wait_slice = [&](int t) {  // this wave's DMAs of slice t have landed (younger slices may be in flight)
-    if (t >= nk) return;
-    if (t + 2 < nk) wait_vm<2 * NDMA>();
-    else if (t + 1 < nk) wait_vm<NDMA>();
-    else wait_vm<0>();
-  };
-#define BAR()                           \
-  do {                                  \
-    __builtin_amdgcn_sched_barrier(0);  \
-    __builtin_amdgcn_s_barrier();       \
-    __builtin_amdgcn_sched_barrier(0);  \
-  } while (0)
-
-  issue(0);
-  if (nk > 1) issue(1);
-  if (nk > 2) issue(2);
-  wait_slice(0);
-  BAR();
-  if (wave < 4) {
-    for (int t = 0; t < nk; ++t) {
-      if (t + 3 < nk) issue(t + 3);
-      ldfrags(t);
-      BAR();
-      mfmas();
-      wait_slice(t + 1);
-      BAR();
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][i], fb[kc & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  } else {
-    for (int t = 0; t < nk; ++t) {
-      if (t > 0) mfmas();
-      BAR();
-      if (t + 3 < nk) issue(t + 3);
-      ldfrags(t);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot t may be refilled after the next barrier
-      wait_slice(t + 1);
-      BAR();
-    }
-    mfmas();
   }
-#undef BAR
 
   const int64_t mw = m0 + wm * WROWS;  // this wave's WROWS x 64 sub-tile
   const int64_t nw = n0 + wn * 64;

@@ -83,14 +83,16 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const void* __restrict__ dres, void* __restrict__ dx,
-                                                            float* __restrict__ part, int64_t rows, int cols, int dyd,
-                                                            int xd, int dxd) {
+                                                            void* __restrict__ dx2, float* __restrict__ part,
+                                                            int64_t rows, int cols, int dyd, int xd, int dxd) {
   __shared__ float red[WAVES][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int nv = NV;
-  f32x4 ag[NV], ab[NV];
+  f32x4 ag[NV], ab[NV], ar[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < NV; ++i) {
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ar[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < rows; row += (int64_t)gridDim.x * WAVES) {
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NV], gg[NV];
@@ -124,19 +126,20 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
         if (dres) {
           const f32x4 r = load4(dres, dxd, row * cols + c);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += r[j];
+          for (int j = 0; j < 4; ++j) { o[j] += r[j]; ar[i][j] += r[j]; }
         }
         store4(dx, dxd, row * cols + c, o);
+        if (dx2) store4(dx2, SEGCLIP_BF16, row * cols + c, o);
       }
     }
   }
-  // block partials: part[blockIdx][0][cols] = dgamma, part[blockIdx][1][cols] = dbeta
+  // block partials: part[blockIdx][0] = dgamma, [1] = dbeta, [2] = column sums of dres
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = pass == 0 ? ag[i][j] : ab[i][j];
+      for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = pass == 0 ? ag[i][j] : (pass == 1 ? ab[i][j] : ar[i][j]);
       __syncthreads();
       if (wave == 0) {
         const int c = (lane + 64 * i) * 4;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) t += red[w][lane * 4 + j];
-            part[((int64_t)blockIdx.x * 2 + pass) * cols + c + j] = t;
+            part[((int64_t)blockIdx.x * 3 + pass) * cols + c + j] = t;
           }
         }
       }
@@ -154,22 +157,24 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
   }
 }
 
-// out[c] = sum_b part[b][c] over the 2*cols columns (dgamma | dbeta); block = 64 columns x 16 row lanes
+// out[c] = sum_b part[b][c] over the 3*cols columns (dgamma | dbeta | colsum(dres)); 64 columns x 16 row lanes
 __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                                          float* __restrict__ out1, int nb, int cols) {
+                                                          float* __restrict__ out1, float* __restrict__ out2, int nb,
+                                                          int cols) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const int width = out2 ? 3 * cols : 2 * cols;
   float s = 0.f;
-  if (c < 2 * cols)
-    for (int b = rl; b < nb; b += 16) s += part[(int64_t)b * 2 * cols + c];
+  if (c < width)
+    for (int b = rl; b < nb; b += 16) s += part[(int64_t)b * 3 * cols + c];
   red[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && c < 2 * cols) {
+  if (rl == 0 && c < width) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cl];
-    if (c < cols) out0[c] = t; else out1[c - cols] = t;
+    if (c < cols) out0[c] = t; else if (c < 2 * cols) out1[c - cols] = t; else out2[c - 2 * cols] = t;
   }
 }
 
@@ -199,28 +204,28 @@ extern "C" int segclip_layernorm_fwd(const void* x, const float* gamma, const fl
 }
 
 extern "C" size_t segclip_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols) {
-  return (size_t)ln_blocks(rows) * 2 * cols * sizeof(float);
+  return (size_t)ln_blocks(rows) * 3 * cols * sizeof(float);
 }
 
 extern "C" int segclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                     const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                     void* ws, int64_t rows, int64_t cols, int dy_dtype, int x_dtype, int dx_dtype,
-                                     void* stream) {
+                                     const float* rstd, const void* dres, void* dx, void* dx_bf16, float* dgamma,
+                                     float* dbeta, float* dres_colsum, void* ws, int64_t rows, int64_t cols,
+                                     int dy_dtype, int x_dtype, int dx_dtype, void* stream) {
   SEGCLIP_REQUIRE(cols % 4 == 0 && cols <= MAXV * 256, "layernorm: cols=%lld must be a multiple of 4 and <= %d",
                   (long long)cols, MAXV * 256);
   SEGCLIP_REQUIRE(ws != nullptr, "layernorm_bwd: workspace required");
   if (rows == 0) return 0;
   const int nb = ln_blocks(rows);
 #define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(nb), dim3(WAVES * 64), 0, (hipStream_t)stream, dy, x, gamma, \
-                                   mean, rstd, dres, dx, (float*)ws, rows, (int)cols, dy_dtype, x_dtype, dx_dtype)
+                                   mean, rstd, dres, dx, dx_bf16, (float*)ws, rows, (int)cols, dy_dtype, x_dtype, dx_dtype)
   switch ((int)cdiv(cols / 4, 64)) {
     case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break;
     case 5: case 6: LNB(6); break; default: LNB(8); break;
   }
 #undef LNB
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, (hipStream_t)stream,
-                     (const float*)ws, dgamma, dbeta, nb, (int)cols);
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)cdiv(3 * cols, 64)), dim3(1024), 0, (hipStream_t)stream,
+                     (const float*)ws, dgamma, dbeta, dres ? dres_colsum : nullptr, nb, (int)cols);
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd_reduce");
   return 0;
 }

@@ -173,7 +173,8 @@ def p_ln_fwd(x, w, b, eps, out_dtype):
     return y, mean, rstd
 
 
-def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None):
+def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, want_dres_colsum=False):
+    """-> dx, dgamma, dbeta [, dx_bf16] [, colsum(dres)]"""
     lib = L.load()
     dy = dy.contiguous()
     rows, cols = x.shape
@@ -181,15 +182,22 @@ def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None):
     dx = _empty((rows, cols), dx_dtype, x)
     dw = _empty((cols,), torch.float32, x)
     db = _empty((cols,), torch.float32, x)
+    dx16 = _empty((rows, cols), torch.bfloat16, x) if want_bf16 else None
+    dsum = _empty((cols,), torch.float32, x) if (want_dres_colsum and dres is not None) else None
     if dres is not None:
         dres = dres.contiguous()
         if dres.dtype != dx_dtype:
             raise TypeError("layernorm_bwd: dres dtype must equal dx dtype")
     ws = torch.empty(max(lib.segclip_layernorm_bwd_ws_bytes(rows, cols), 4), dtype=torch.uint8, device=x.device)
     L.check(lib.segclip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
-                                      L.ptr(dw), L.ptr(db), L.ptr(ws), rows, cols, L.dt(dy), L.dt(x), L.dt(dx),
-                                      L.stream()), "layernorm_bwd")
-    return dx, dw, db
+                                      L.ptr(dx16), L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws), rows, cols, L.dt(dy),
+                                      L.dt(x), L.dt(dx), L.stream()), "layernorm_bwd")
+    out = [dx, dw, db]
+    if want_bf16:
+        out.append(dx16)
+    if want_dres_colsum:
+        out.append(dsum)
+    return tuple(out)
 
 
 def _attn_desc(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, scale, causal, q_off=0, k_off=0, v_off=0):
@@ -247,7 +255,7 @@ class LayerNormFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
-        dx, dw, db = p_ln_bwd(dy, x, w, mean, rstd, None, x.dtype)
+        dx, dw, db = p_ln_bwd(dy, x, w, mean, rstd, None, x.dtype)[:3]
         return dx, dw, db, None, None
 
 
@@ -406,18 +414,27 @@ class ResBlockFn(Function):
         hd = D // n_head
         g = g.contiguous().view(M, D)
         need = ctx.needs_input_grad
+        bf = act_dtype == torch.bfloat16
+        # bf16 mode: the fp32 residual-stream gradients feed the GEMMs as bf16 copies (all GEMMs then run on the
+        # LDS-DMA kernel and read half the bytes); the copy of dx comes for free out of the LayerNorm backward and
+        # is handed to the next block through a side channel on the gradient tensor.
+        g16 = g
+        if bf:
+            st = getattr(g, "_segclip_bf16", None)
+            g16 = st if (st is not None and st.shape == g.shape and st.device == g.device) else p_cast(g, act_dtype)
         # ---- MLP
-        du = p_dgrad(g, wpr_c, act_dtype, aux=u, act=act)          # (dy c_proj) * act'(u)
-        dwpr = p_wgrad(g, h) if need[11] else None
-        dbpr = p_colsum(g) if need[12] else None
+        du = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act)          # (dy c_proj) * act'(u)
+        dwpr = p_wgrad(g16, h) if need[11] else None
         dy2 = p_dgrad(du, wfc_c, act_dtype)
         dwfc = p_wgrad(du, y2) if need[9] else None
         dbfc = p_colsum(du) if need[10] else None
-        dx1, dln2w, dln2b = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32)
+        r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
+        dx1, dln2w, dln2b = r[0], r[1], r[2]
+        dx1_16 = r[3] if bf else dx1
+        dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
         # ---- attention
-        do = p_dgrad(dx1, wo_c, act_dtype)
-        dwo = p_wgrad(dx1, o) if need[5] else None
-        dbo = p_colsum(dx1) if need[6] else None
+        do = p_dgrad(dx1_16, wo_c, act_dtype)
+        dwo = p_wgrad(dx1_16, o) if need[5] else None
         dqkv = _empty((M, 3 * D), act_dtype, g)
         s3 = (T * 3 * D, 3 * D)
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
@@ -426,8 +443,13 @@ class ResBlockFn(Function):
         dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
         dwqkv = p_wgrad(dqkv, y1) if need[3] else None
         dbqkv = p_colsum(dqkv) if need[4] else None
-        dx, dln1w, dln1b = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32)
-        return (dx.view(B, T, D), dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr, None,
+        r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
+        dx, dln1w, dln1b = r[0], r[1], r[2]
+        dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
+        dx = dx.view(B, T, D)
+        if bf:
+            dx._segclip_bf16 = r[3].view(B, T, D)
+        return (dx, dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr, None,
                 None, None, None, None)
 
 

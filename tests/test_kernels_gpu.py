@@ -122,9 +122,12 @@ def test_layernorm_fwd_bwd(cols, xdt, ydt):
     close(y, ref, rt, at, "ln fwd")
     dy = rnd(rows, cols, dtype=ydt, seed=34)
     dres = rnd(rows, cols, dtype=F32, seed=35)
-    dx, dw, db = ops.p_ln_bwd(dy, x, w, mean, rstd, dres=dres, dx_dtype=F32)
+    dx, dw, db, dx16, dsum = ops.p_ln_bwd(dy, x, w, mean, rstd, dres=dres, dx_dtype=F32, want_bf16=True,
+                                          want_dres_colsum=True)
     ref.backward(dy.float())
     close(dx, xr.grad + dres, 1e-4, 1e-4, "ln dx")
+    assert torch.equal(dx16, dx.to(BF))
+    close(dsum, dres.sum(0), 1e-5, 1e-4, "ln colsum(dres)")
     close(dw, wr.grad, 1e-4, 1e-3, "ln dgamma")
     close(db, br.grad, 1e-4, 1e-3, "ln dbeta")
 
