@@ -135,9 +135,14 @@ def main():
         tsum = sum(r[0] for r in rec)
         fsum = sum(r[1] for r in rec)
         big = [r for r in rec if r[1] >= 1e11]
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(fsum / tsum / 1e12, 1),
+        traffic = None  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/)
+        tf = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if a.batch == 256 and a.spec == "vitb16" and not a.full_loss and os.path.exists(tf):
+            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback)",
+                    "achieved": round(fsum / tsum / 1e12, 1),
                     "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(fsum / tsum / 1e12 / PEAK_BF16_TF, 4),
-                    "traffic": None, "launches_per_step": len(rec), "avg_launch_us": round(tsum / len(rec) * 1e6, 1),
+                    "traffic": traffic, "algorithmic_flops_per_launch": round(fsum / len(rec)), "launches_per_step": len(rec), "avg_launch_us": round(tsum / len(rec) * 1e6, 1),
                     "gemm_share_of_step": round(tsum * 1e3 / ms, 3),
                     "large_gemm_tflops": round(sum(r[1] for r in big) / max(sum(r[0] for r in big), 1e-9) / 1e12, 1),
                     "step_frac": round(pairs / world * GF_PER_PAIR_FWD_BWD / 1e3 / PEAK_BF16_TF, 4)}
