@@ -50,22 +50,39 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* t, int rbase, int cbase,
   return __builtin_bit_cast(bf16x8_t, r);
 }
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
-  s16x8 r;
+  u32x4 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(p[j]);
+  for (int j = 0; j < 4; ++j) r[j] = pack2bf(p[2 * j], p[2 * j + 1]);
   return __builtin_bit_cast(bf16x8_t, r);
 }
 // accumulator row index of register r for half h (32x32 tile)
 __device__ __forceinline__ int accrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// stage `nrows_pad` rows (zero-filled beyond nvalid / beyond hd) of X[row*st + d] into a swizzled tile
+// stage `nrows_pad` rows (zero-filled beyond nvalid / beyond hd) of X[row*st + d] into a swizzled tile.
+// Loads are unconditional from clamped addresses and issued in batches of 4 before any LDS write (a load
+// inside a divergent branch is waited for individually by hipcc and the staging becomes latency-serial).
 __device__ __forceinline__ void stage_rows(char* tile, const bf16_t* __restrict__ X, int64_t st, int row0, int nvalid,
                                            int nrows_pad, int hd, int tid, int nthreads) {
-  for (int idx = tid; idx < nrows_pad * 8; idx += nthreads) {
-    const int r = idx >> 3, c = idx & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < nvalid && c * 8 < hd) v = *reinterpret_cast<const u32x4*>(X + (int64_t)(row0 + r) * st + c * 8);
-    *reinterpret_cast<u32x4*>(tile + swz(r, c * 8)) = v;
+  const int total = nrows_pad * 8;
+  for (int base = 0; base < total; base += 4 * nthreads) {
+    u32x4 v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = base + it * nthreads + tid;
+      const int r = idx >> 3, c = idx & 7;
+      const int rc = r < nvalid ? r : nvalid - 1;
+      const int cc = c * 8 < hd ? c : 0;
+      v[it] = *reinterpret_cast<const u32x4*>(X + (int64_t)(row0 + rc) * st + cc * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = base + it * nthreads + tid;
+      const int r = idx >> 3, c = idx & 7;
+      if (idx < total) {
+        const bool ok = r < nvalid && c * 8 < hd;
+        *reinterpret_cast<u32x4*>(tile + swz(r, c * 8)) = ok ? v[it] : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
   }
 }
 
@@ -95,9 +112,10 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
   bf16x8_t qf[4];
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
-    u32x4 v = {0u, 0u, 0u, 0u};
     const int d = kc * 16 + 8 * lh;
-    if (qg < a.Tq && d < a.hd) v = *reinterpret_cast<const u32x4*>(Qp + (int64_t)qg * a.q_st + d);
+    const bool ok = qg < a.Tq && d < a.hd;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(Qp + (int64_t)(qg < a.Tq ? qg : a.Tq - 1) * a.q_st + (d < a.hd ? d : 0));
+    const u32x4 v = ok ? raw : u32x4{0u, 0u, 0u, 0u};
     qf[kc] = __builtin_bit_cast(bf16x8_t, v);
   }
   f32x16 o[2];
@@ -219,25 +237,42 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
   stage_rows(Qt, Qp, a.q_st, 0, a.Tq, tqp, a.hd, tid, blockDim.x);
   stage_rows(Kt, Kp, a.k_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
   stage_rows(Vt, Vp, a.v_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
-  // dO tile + D[q] = sum_d dO*O (8 consecutive lanes share a row)
-  for (int idx = tid; idx < tqp * 8; idx += blockDim.x) {
-    const int r = idx >> 3, c = idx & 7;
-    u32x4 g = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
-    if (r < a.Tq && c * 8 < a.hd) {
-      g = *reinterpret_cast<const u32x4*>(Gp + (int64_t)r * a.do_st + c * 8);
-      ov = *reinterpret_cast<const u32x4*>(Op + (int64_t)r * a.o_st + c * 8);
-    }
-    *reinterpret_cast<u32x4*>(Gt + swz(r, c * 8)) = g;
-    float s = 0.f;
+  // dO tile + D[q] = sum_d dO*O (8 consecutive lanes share a row); branch-free batched loads as in stage_rows
+  {
+    const int total = tqp * 8;
+    for (int base = 0; base < total; base += 2 * (int)blockDim.x) {
+      u32x4 gv[2], ov[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s += __uint_as_float(g[j] << 16) * __uint_as_float(ov[j] << 16);
-      s += __uint_as_float(g[j] & 0xffff0000u) * __uint_as_float(ov[j] & 0xffff0000u);
-    }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if (c == 0) {
-      Ds[r] = s;
-      Ls[r] = r < a.Tq ? a.lse[((int64_t)b * a.H + h) * a.Tq + r] : 0.f;
+      for (int it = 0; it < 2; ++it) {
+        const int idx = base + it * (int)blockDim.x + tid;
+        const int r = idx >> 3, c = idx & 7;
+        const int rc = r < a.Tq ? r : a.Tq - 1;
+        const int cc = c * 8 < a.hd ? c : 0;
+        gv[it] = *reinterpret_cast<const u32x4*>(Gp + (int64_t)rc * a.do_st + cc * 8);
+        ov[it] = *reinterpret_cast<const u32x4*>(Op + (int64_t)rc * a.o_st + cc * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = base + it * (int)blockDim.x + tid;
+        const int r = idx >> 3, c = idx & 7;
+        const bool ok = r < a.Tq && c * 8 < a.hd;
+        const u32x4 g = ok ? gv[it] : u32x4{0u, 0u, 0u, 0u};
+        const u32x4 o4 = ok ? ov[it] : u32x4{0u, 0u, 0u, 0u};
+        float sdot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sdot += __uint_as_float(g[j] << 16) * __uint_as_float(o4[j] << 16);
+          sdot += __uint_as_float(g[j] & 0xffff0000u) * __uint_as_float(o4[j] & 0xffff0000u);
+        }
+        sdot += __shfl_xor(sdot, 1, 64); sdot += __shfl_xor(sdot, 2, 64); sdot += __shfl_xor(sdot, 4, 64);
+        if (idx < total) {
+          *reinterpret_cast<u32x4*>(Gt + swz(r, c * 8)) = g;
+          if (c == 0) {
+            Ds[r] = sdot;
+            Ls[r] = r < a.Tq ? a.lse[((int64_t)b * a.H + h) * a.Tq + r] : 0.f;
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -263,12 +298,18 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
       }
       float p[16], ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = q0 + accrow(r, lh);
-        const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
-        const float pv = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
-        p[r] = pv;
-        ds[r] = pv * (dp[r] - Ds[q]) * a.scale;
+      for (int rg = 0; rg < 4; ++rg) {
+        const int qb = q0 + 8 * rg + 4 * lh;  // 4 consecutive query rows per register group
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = rg * 4 + j, q = qb + j;
+          const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
+          const float pv = ok ? __expf(s[r] * a.scale - l4[j]) : 0.f;
+          p[r] = pv;
+          ds[r] = pv * (dp[r] - d4[j]) * a.scale;
+        }
       }
       const bf16x8_t pb0 = pack8(p), pb1 = pack8(p + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
 #pragma unroll

@@ -137,64 +137,88 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
       bias[c] = b[0]; bias[c + 1] = b[1]; bias[c + 2] = b[2]; bias[c + 3] = b[3];
     }
   }
+  // rows are processed in batches of 4 iterations: the residual / pre-activation loads of a batch are all
+  // issued before the first use (one exposed memory latency per batch instead of one per row)
+  constexpr int NIT = 64 / RPI, BATCH = 4;
+  constexpr int RW = W / 4;  // 16-byte words per lane for an fp32 side operand
 #pragma unroll 1
-  for (int it = 0; it < 64 / RPI; ++it) {
-    const int row = it * RPI + rl;
-    const int64_t m = mw + row;
-    float v[W];
+  for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+    f32x4 side_f[BATCH][RW];   // fp32 residual
+    u32x4 side_h[BATCH];       // bf16 residual (W==8) / bf16 aux
+    u32x2 side_q[BATCH];       // bf16 residual when W==4
+    f32x4 aux_f[BATCH];        // fp32 aux (W==4)
 #pragma unroll
-    for (int c = 0; c < W; c += 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
-      v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
-    }
-    if (MODE == EPI_DACT) {
-      float u[W];
-      if (sizeof(CT) == 2) unpack8(*reinterpret_cast<const u32x4*>((const bf16_t*)g.aux + coff + m * g.ldaux + n), u);
-      else { const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)g.aux + coff + m * g.ldaux + n);
-             u[0] = a[0]; u[1] = a[1]; u[2] = a[2]; u[3] = a[3]; }
-#pragma unroll
-      for (int c = 0; c < W; ++c) v[c] *= apply_act_grad(g.act, u[c]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < W; ++c) v[c] += bias[c];
-      if (MODE == EPI_ACT) {
-        if (g.aux) {
-          if (sizeof(CT) == 2) {
-            u32x4 p; for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-            *reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n) = p;
-          } else {
-            *reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < W; ++c) v[c] = apply_act(g.act, v[c]);
-      }
-      if (g.residual) {
+    for (int bi = 0; bi < BATCH; ++bi) {
+      const int64_t m = mw + (it0 + bi) * RPI + rl;
+      if (MODE == EPI_DACT) {
+        if (sizeof(CT) == 2) side_h[bi] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.aux + coff + m * g.ldaux + n);
+        else aux_f[bi] = *reinterpret_cast<const f32x4*>((const float*)g.aux + coff + m * g.ldaux + n);
+      } else if (g.residual) {
         const int64_t o = roff + m * g.ldr + n;
         if (g.r_dtype == SEGCLIP_BF16) {
-          float rr[8];
-          if (W == 8) { unpack8(*reinterpret_cast<const u32x4*>((const bf16_t*)g.residual + o), rr); }
-          else { const u32x2 q = *reinterpret_cast<const u32x2*>((const bf16_t*)g.residual + o);
-                 rr[0] = __uint_as_float(q[0] << 16); rr[1] = __uint_as_float(q[0] & 0xffff0000u);
-                 rr[2] = __uint_as_float(q[1] << 16); rr[3] = __uint_as_float(q[1] & 0xffff0000u); }
-#pragma unroll
-          for (int c = 0; c < W; ++c) v[c] += rr[c];
+          if (W == 8) side_h[bi] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.residual + o);
+          else side_q[bi] = *reinterpret_cast<const u32x2*>((const bf16_t*)g.residual + o);
         } else {
 #pragma unroll
-          for (int c = 0; c < W; c += 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)g.residual + o + c);
-            v[c] += a[0]; v[c + 1] += a[1]; v[c + 2] += a[2]; v[c + 3] += a[3];
-          }
+          for (int c = 0; c < RW; ++c) side_f[bi][c] = *reinterpret_cast<const f32x4*>((const float*)g.residual + o + 4 * c);
         }
       }
     }
-    if (sizeof(CT) == 2) {
-      u32x4 p;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-      *reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n) = p;
-    } else {
-      *reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+    for (int bi = 0; bi < BATCH; ++bi) {
+      const int row = (it0 + bi) * RPI + rl;
+      const int64_t m = mw + row;
+      float v[W];
+#pragma unroll
+      for (int c = 0; c < W; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
+        v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
+      }
+      if (MODE == EPI_DACT) {
+        float u[8];
+        if (sizeof(CT) == 2) unpack8(side_h[bi], u);
+        else { u[0] = aux_f[bi][0]; u[1] = aux_f[bi][1]; u[2] = aux_f[bi][2]; u[3] = aux_f[bi][3]; }
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] *= apply_act_grad(g.act, u[c]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] += bias[c];
+        if (MODE == EPI_ACT) {
+          if (g.aux) {
+            if (sizeof(CT) == 2) {
+              u32x4 p;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+              *reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n) = p;
+            } else {
+              *reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < W; ++c) v[c] = apply_act(g.act, v[c]);
+        }
+        if (g.residual) {
+          if (g.r_dtype == SEGCLIP_BF16) {
+            float rr[8];
+            if (W == 8) unpack8(side_h[bi], rr);
+            else { rr[0] = __uint_as_float(side_q[bi][0] << 16); rr[1] = __uint_as_float(side_q[bi][0] & 0xffff0000u);
+                   rr[2] = __uint_as_float(side_q[bi][1] << 16); rr[3] = __uint_as_float(side_q[bi][1] & 0xffff0000u); }
+#pragma unroll
+            for (int c = 0; c < W; ++c) v[c] += rr[c];
+          } else {
+#pragma unroll
+            for (int c = 0; c < W; ++c) v[c] += side_f[bi][c / 4][c % 4];
+          }
+        }
+      }
+      if (sizeof(CT) == 2) {
+        u32x4 p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+        *reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n) = p;
+      } else {
+        *reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+      }
     }
   }
 }
