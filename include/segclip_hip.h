@@ -75,6 +75,10 @@ typedef struct segclip_gemm_desc {
   int32_t reserved;
   void* ws;         /* optional split-K scratch (bf16 path, plain epilogue only); NULL = no split-K */
   int64_t ws_bytes; /* size of ws; segclip_gemm_ws_bytes(d) is the amount that enables split-K */
+  float* colsum;    /* optional [N] fp32: column sums of the stored C (bias gradient fused into the epilogue).
+                       Needs colsum_ws = (M/64)*N floats, M % 256 == 0, N % 256 == 0 and the LDS-DMA bf16 path;
+                       otherwise segclip_gemm returns SEGCLIP_ERR_UNSUPPORTED without launching. */
+  float* colsum_ws;
 } segclip_gemm_desc;
 
 size_t segclip_gemm_ws_bytes(const segclip_gemm_desc* d);

@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("bsR1", i64), ("bsR2", i64),
                 ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("r_dtype", i32),
                 ("act", i32), ("mul_dact", i32), ("alpha", f32), ("reserved", i32),
-                ("ws", vp), ("ws_bytes", i64)]
+                ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp)]
 
 
 class AttnDesc(C.Structure):

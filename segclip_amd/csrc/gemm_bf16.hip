@@ -293,6 +293,25 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, in
   }
 }
 
+// out[c] = sum_r part[r][c]; block = 64 columns x 16 row lanes (deterministic)
+__global__ __launch_bounds__(1024) void colsum_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                 int64_t rows, int64_t N) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < N)
+    for (int64_t r = rl; r < rows; r += 16) s += part[r * N + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    out[c] = t;
+  }
+}
+
 }  // namespace
 
 bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t kper, int64_t nb,
@@ -369,10 +388,23 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   if (g.splits > 1) g.splits = (int)cdiv(d->K, g.kper);
   g.slab = (float*)d->ws;
   g.vec_epi = 0;
+  g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
   const bool fast = aligned16(d);
   bool launched = false;
+  if (d->colsum) {
+    SEGCLIP_REQUIRE(d->colsum_ws != nullptr, "gemm: colsum needs colsum_ws");
+    if (!(want_dma(d) && d->M % 256 == 0 && d->N % 256 == 0 && g.splits == 1 && nb == 1)) {
+      segclip_set_error("gemm: fused colsum unsupported for this shape");
+      return SEGCLIP_ERR_UNSUPPORTED;
+    }
+    g.colsum_part = d->colsum_ws;
+  }
   if (want_dma(d)) launched = segclip_gemm_bf16_dma_try(d, &g, g.splits, g.kper, nb, stream);
+  if (d->colsum && (!launched || !g.colsum_part)) {
+    segclip_set_error("gemm: fused colsum unsupported for this shape");
+    return SEGCLIP_ERR_UNSUPPORTED;
+  }
   if (!launched) {
 #define LAUNCH(AK, BKS, AF)                                                                                         \
   do {                                                                                                              \
@@ -386,6 +418,11 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
 #undef LAUNCH
   }
   SEGCLIP_CHECK_LAUNCH("gemm_bf16");
+  if (d->colsum) {
+    hipLaunchKernelGGL(colsum_part_reduce_kernel, dim3((unsigned)cdiv(d->N, 64)), dim3(1024), 0, stream,
+                       (const float*)d->colsum_ws, d->colsum, d->M / 64, d->N);
+    SEGCLIP_CHECK_LAUNCH("gemm_colsum_reduce");
+  }
   if (g.splits > 1) {
     const int64_t total = nb * d->M * d->N;
     const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);

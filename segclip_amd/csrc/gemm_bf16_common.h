@@ -13,6 +13,7 @@ struct Args {
   int c_dtype, r_dtype, act, mul_dact; float alpha;
   int nbx, nby;
   int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
+  float* colsum_part;  // optional [M/64][N] fp32 partial column sums of the stored output (LDS epilogue only)
   int vec_epi;  // host-checked: every C / aux / residual / bias access of a full tile may be a 16-byte vector
 };
 
@@ -139,6 +140,9 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
   }
   // rows are processed in batches of 4 iterations: the residual / pre-activation loads of a batch are all
   // issued before the first use (one exposed memory latency per batch instead of one per row)
+  float csum[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) csum[c] = 0.f;
   constexpr int NIT = 64 / RPI, BATCH = 4;
   constexpr int RW = W / 4;  // 16-byte words per lane for an fp32 side operand
 #pragma unroll 1
@@ -211,6 +215,8 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
           }
         }
       }
+#pragma unroll
+      for (int c = 0; c < W; ++c) csum[c] += v[c];
       if (sizeof(CT) == 2) {
         u32x4 p;
 #pragma unroll
@@ -219,6 +225,15 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
       } else {
         *reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
       }
+    }
+  }
+  if (g.colsum_part) {  // column sums of this wave's 64 rows (bias gradient of the producing Linear)
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      float x = csum[c];
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+      if (rl == 0) g.colsum_part[(mw >> 6) * g.N + n + c] = x;
     }
   }
 }

@@ -260,12 +260,14 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   g.nby = (int)cdiv(d->M, BM);
   g.splits = splits;
   g.kper = kper;
+  if (g.colsum_part && bn != 256 && d->N % 128 != 0) return false;
   {
     auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int64_t ce = d->c_dtype == SEGCLIP_BF16 ? 8 : 4, re = d->r_dtype == SEGCLIP_BF16 ? 8 : 4;
     g.vec_epi = al(d->C) && al(d->aux) && al(d->residual) && al(d->bias) && d->ldc % ce == 0 &&
                 (!d->aux || d->ldaux % ce == 0) && (!d->residual || d->ldr % re == 0) && d->bsC1 % ce == 0 &&
                 d->bsC2 % ce == 0 && (!d->residual || (d->bsR1 % re == 0 && d->bsR2 % re == 0));
+    if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
 #define GO(AK, BKS)                                                                                          \

@@ -55,7 +55,7 @@ def _off(t, off):
 # ------------------------------------------------------------------------------------------------
 def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=None, residual=None, ldr=0,
            r_off=0, aux=None, ldaux=0, act=ACT_NONE, mul_dact=False, alpha=1.0, nb1=1, nb2=1, bsA=(0, 0),
-           bsB=(0, 0), bsC=(0, 0), bsR=None):
+           bsB=(0, 0), bsC=(0, 0), bsR=None, colsum=None):
     """C(m,n) = epi(alpha * sum_k A(m,k) B(n,k)); sa = (sam, sak), sb = (sbn, sbk) element strides."""
     lib = L.load()
     L.require_cuda(A, B, Cc)
@@ -78,6 +78,9 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     if aux is not None and aux.dtype != Cc.dtype:
         raise TypeError("gemm: aux dtype must equal output dtype")
     d.act, d.mul_dact, d.alpha = act, int(mul_dact), float(alpha)
+    if colsum is not None:
+        csws = torch.empty((max(M // 64, 1), N), dtype=torch.float32, device=A.device)
+        d.colsum, d.colsum_ws = L.ptr(colsum), L.ptr(csws)
     ws = None
     nbytes = lib.segclip_gemm_ws_bytes(C.byref(d))
     if nbytes:
@@ -122,15 +125,27 @@ def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_d
     return y, aux
 
 
-def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False):
-    """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)."""
+def fused_colsum_ok(M, N, K, dtype):
+    """Shapes for which the bf16 LDS-DMA GEMM can emit the column sums of its output in the epilogue."""
+    return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0
+
+
+def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False):
+    """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)
+    want_colsum: also return the column sums of dx (= bias gradient of the Linear that produced the
+    pre-activation), fused into the GEMM epilogue when the shape allows, else by the colsum kernel."""
     M, N = dy.shape
     K = w.shape[0] if w_kn else w.shape[1]
     dx = _empty((M, K), out_dtype, dy)
     sb = (w.stride(0), 1) if w_kn else (1, w.stride(0))
     if aux is not None and aux.dtype != out_dtype:
         raise TypeError("dgrad: aux dtype must equal output dtype")
-    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None)
+    cs = None
+    if want_colsum and fused_colsum_ok(M, K, N, out_dtype) and dy.dtype == torch.bfloat16:
+        cs = _empty((K,), torch.float32, dy)
+    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None, colsum=cs)
+    if want_colsum:
+        return dx, (cs if cs is not None else p_colsum(dx))
     return dx
 
 
@@ -423,11 +438,10 @@ class ResBlockFn(Function):
             st = getattr(g, "_segclip_bf16", None)
             g16 = st if (st is not None and st.shape == g.shape and st.device == g.device) else p_cast(g, act_dtype)
         # ---- MLP
-        du = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act)          # (dy c_proj) * act'(u)
+        du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True)  # (dy c_proj)*act'(u), colsum
         dwpr = p_wgrad(g16, h) if need[11] else None
         dy2 = p_dgrad(du, wfc_c, act_dtype)
         dwfc = p_wgrad(du, y2) if need[9] else None
-        dbfc = p_colsum(du) if need[10] else None
         r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
         dx1, dln2w, dln2b = r[0], r[1], r[2]
         dx1_16 = r[3] if bf else dx1

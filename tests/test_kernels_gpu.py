@@ -74,6 +74,19 @@ def test_gemm_dgrad_wgrad_layouts(dtype, M, N, K):
     close(ops.p_wgrad(dy, x, w_kn=True), x.float().t() @ dy.float(), rt, at * math.sqrt(M / 64 + 1), "w_kn wgrad")
 
 
+def test_gemm_fused_colsum_epilogue():
+    """dgrad * act'(u) with the bias-gradient column sums produced by the LDS epilogue."""
+    M, N, K = 512, 256, 512
+    dy, w, u = rnd(M, N, dtype=BF, seed=14), rnd(N, K, dtype=BF, seed=15, scale=N ** -0.5), rnd(M, K, dtype=BF, seed=16)
+    du, cs = ops.p_dgrad(dy, w, BF, aux=u, act=ops.ACT_QUICK_GELU, want_colsum=True)
+    s = torch.sigmoid(1.702 * u.float())
+    ref = (dy.float() @ w.float()) * (s * (1 + 1.702 * u.float() * (1 - s)))
+    close(du, ref, 2e-2, 2e-2, "du")
+    close(cs, ref.sum(0), 2e-2, 0.05, "fused colsum")
+    du2, cs2 = ops.p_dgrad(dy[:200], w, BF, aux=u[:200].contiguous(), act=ops.ACT_QUICK_GELU, want_colsum=True)  # fallback path
+    close(cs2, ref[:200].sum(0), 2e-2, 0.05, "fallback colsum")
+
+
 def test_gemm_bf16_fp32_A_operand_and_splitk():
     """fp32 residual-stream gradients as the A operand of the bf16 kernels; split-K wgrad (M >> tiles)."""
     M, N, K = 6272, 256, 128
