@@ -781,8 +781,8 @@ class AllGatherFn(Function):
 
     @staticmethod
     def forward(ctx, x):
-        ctx.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if ctx.world == 1:
+        ctx.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0
+        if ctx.world == 0:   # no process group: single-process run, identity
             return x
         x = x.contiguous()
         out = torch.empty((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -791,7 +791,7 @@ class AllGatherFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.world == 1:
+        if ctx.world == 0:
             return g
         g = g.contiguous()
         n = g.shape[0] // ctx.world

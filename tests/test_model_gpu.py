@@ -147,3 +147,69 @@ def test_full_size_properties_bf16():
     finally:
         segclip_amd.set_compute_dtype(torch.float32)
         segclip_amd.set_cross_mode("t18")
+
+
+def test_eval_mode_encoders_match_oracle():
+    """Inference subset: model.eval() -> forward returns None; encode_image (no Gumbel noise, soft_attn for the
+    segmentation tier) and encode_text match the oracle's eval restatement."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["tiny"]
+    segclip_amd.set_compute_dtype(torch.float32)
+    model, _ = synth.build_model(spec, {}, device=DEV)
+    model.eval()
+    batch = synth.synthetic_batch(spec, 3, seed=9, device=DEV, with_seg=False)
+    with torch.no_grad():
+        assert model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"]) is None
+        feat, hidden, mid = model.clip.encode_image(batch["image"][:, 0], return_hidden=True)
+        tfeat = model.clip.encode_text(batch["input_ids"][:, 0])
+        tfeat2, thidden = model.clip.encode_text(batch["input_ids"][:, 0], return_hidden=True)
+    P = oracle_params(spec, model_param_shapes(spec, {}), requires_grad=False)
+    cb = synth.synthetic_batch(spec, 3, seed=9, with_seg=False)
+    of, oh, _, _, omid = so.encode_image(cb["image"][:, 0], P, spec, gumbel=None)
+    otf, oth, _ = so.encode_text(cb["input_ids"][:, 0], P, spec)
+    assert float((feat.cpu() - of).abs().max()) <= 1e-4
+    assert float((hidden.cpu() - oh).abs().max()) <= 1e-4
+    assert float((mid["attns"][0]["soft_attn"].cpu() - omid["attns"][0]["soft_attn"]).abs().max()) <= 1e-4
+    assert torch.equal(mid["hard_idx"].cpu().long(), omid["hard_idx"])
+    assert float((tfeat.cpu() - otf).abs().max()) <= 1e-4 and float((tfeat2.cpu() - otf).abs().max()) <= 1e-4
+    assert float((thidden.cpu() - oth).abs().max()) <= 1e-4
+
+
+def test_ddp_wrapper_and_rccl_gather_single_rank():
+    """The N>1 code path on one GPU: nccl (RCCL) process group of size 1, DistributedDataParallel with
+    find_unused_parameters (as main_task_align.py:251), fused all-gather / reduce-scatter of the embeddings.
+    Gradients must equal the un-wrapped run."""
+    import os
+    import torch.distributed as dist
+    spec = synth.SPECS["tiny"]
+    segclip_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        model, _ = synth.build_model(spec, {}, device=DEV)
+        batch = synth.synthetic_batch(spec, 4, seed=13, device=DEV, with_seg=False)
+        noise = synth.synthetic_noise(spec, 4, seed=13, device=DEV)
+
+        def run(net):
+            model.zero_grad(set_to_none=True)
+            with segclip_amd.noise_injection([("gumbel", noise["gumbel_main"])]):
+                loss = net(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"])
+            loss.backward()
+            return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        l0, g0 = run(model)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True,
+                                                            gradient_as_bucket_view=True)
+            l1, g1 = run(ddp)
+            l2, g2 = run(ddp)
+        finally:
+            dist.destroy_process_group()
+        assert abs(l0 - l1) <= 1e-6 and abs(l1 - l2) <= 1e-6
+        assert set(g0) == set(g1)
+        for n in g0:
+            assert torch.allclose(g0[n], g1[n], rtol=0, atol=1e-6 * float(g0[n].abs().max()) + 1e-12), n
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
