@@ -14,6 +14,7 @@ import torch
 
 compute_dtype = torch.float32
 cross_mode = "t18"
+overlap_towers = True  # enqueue the text tower on a second HIP stream (concurrent with the vision tower)
 _noise = None
 
 

@@ -8,7 +8,7 @@ from functools import partial
 import torch
 from torch import nn
 
-from .. import ops
+from .. import config, ops
 from .module_clip import CLIP, available_models
 from .module_mae import MAEDecoder
 from .util_module import CrossEn, PreTrainedModel, dist_collect, get_attr, get_logger, show_log
@@ -107,6 +107,13 @@ class SegCLIP(SegCLIPPreTrainedModel):
         self.use_seglabel = get_attr(task_config, "use_seglabel", default_value=False)
         self.apply(self.init_weights)
 
+    def _text_stream(self):
+        st = getattr(self, "_side_stream", None)
+        if st is None or st.device != torch.cuda.current_stream().device:
+            st = torch.cuda.Stream()
+            self.__dict__["_side_stream"] = st
+        return st
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, token_type_ids, attention_mask, image, image_seg=None):
         """modules/modeling.py:174-256.  token_type_ids / attention_mask are accepted and ignored on this
@@ -118,9 +125,22 @@ class SegCLIP(SegCLIPPreTrainedModel):
         image_frame = 1
         if not self.training:
             return None
-        sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
+        # The two towers are independent until the similarity: the text tower (small GEMMs that leave most CUs
+        # idle) is enqueued on a second HIP stream so its kernels fill the gaps of the vision tower; autograd runs
+        # each node's backward on the stream of its forward, so the overlap carries over to the backward pass.
+        if config.overlap_towers:
+            main = torch.cuda.current_stream()
+            side = self._text_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
+        else:
+            sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
         visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
                                                                           return_hidden=True)
+        if config.overlap_towers:
+            main.wait_stream(side)
+            sequence_output.record_stream(main)
         self.last_mid_states = mid_states
         sim_matrix_t2v, sim_matrix_v2t = self._loose_similarity(sequence_output, visual_output)
         offset = sequence_output.size(0) * int(getattr(self.task_config, "rank", 0))
