@@ -8,6 +8,7 @@ from functools import partial
 import torch
 from torch import nn
 
+from .. import _lib as L
 from .. import config, ops
 from .module_clip import CLIP, available_models
 from .module_mae import MAEDecoder
@@ -119,6 +120,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
         """modules/modeling.py:174-256.  token_type_ids / attention_mask are accepted and ignored on this
         path exactly like the reference."""
         input_ids = input_ids.view(-1, input_ids.shape[-1])
+        L.require_cuda(input_ids, torch.as_tensor(image))  # fail loudly: there is no CPU / eager fallback
         image_input = torch.as_tensor(image).float()
         b, pair, channel, h, w = image_input.shape
         image = image_input[:, 0].reshape(b, channel, h, w)
