@@ -14,6 +14,8 @@ import torch
 
 compute_dtype = torch.float32
 cross_mode = "t18"
+overlap_wgrad = False  # weight-gradient GEMMs of a block on a second HIP stream; measured SLOWER (64.4 vs 59.5 ms/step:
+                       # two 139-KiB-LDS GEMMs cannot share a CU and the interleaving delays the dgrad chain), kept off
 overlap_towers = True  # enqueue the text tower on a second HIP stream (concurrent with the vision tower)
 _noise = None
 

@@ -249,6 +249,17 @@ def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0,
     L.check(lib.segclip_attn_bwd(C.byref(d), L.stream()), "attn_bwd")
 
 
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream():
+    dev = torch.cuda.current_device()
+    st = _WGRAD_STREAMS.get(dev)
+    if st is None:
+        st = _WGRAD_STREAMS[dev] = torch.cuda.Stream()
+    return st
+
+
 def wcast(w, act_dtype):
     """Parameter (fp32 master) in the compute dtype of the current mode."""
     return p_cast(w.detach(), act_dtype)
@@ -437,29 +448,48 @@ class ResBlockFn(Function):
         if bf:
             st = getattr(g, "_segclip_bf16", None)
             g16 = st if (st is not None and st.shape == g.shape and st.device == g.device) else p_cast(g, act_dtype)
+        # The weight gradients do not feed the data-gradient chain: they are enqueued on a second HIP stream and
+        # run concurrently with the dgrad / LayerNorm / attention kernels of the chain (their tiles fill the CUs
+        # that the chain's partial last rounds and store phases leave idle).
+        from . import config as _cfg
+        main = torch.cuda.current_stream()
+        side = _wgrad_stream() if _cfg.overlap_wgrad else None
+
+        def on_side(fn, *deps):
+            if side is None:
+                return fn()
+            side.wait_stream(main)           # operands produced on the main stream are ready
+            with torch.cuda.stream(side):
+                out = fn()
+            if out is not None:
+                out.record_stream(main)
+            return out
+
         # ---- MLP
         du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True)  # (dy c_proj)*act'(u), colsum
-        dwpr = p_wgrad(g16, h) if need[11] else None
+        dwpr = on_side(lambda: p_wgrad(g16, h)) if need[11] else None
         dy2 = p_dgrad(du, wfc_c, act_dtype)
-        dwfc = p_wgrad(du, y2) if need[9] else None
+        dwfc = on_side(lambda: p_wgrad(du, y2)) if need[9] else None
         r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
         dx1, dln2w, dln2b = r[0], r[1], r[2]
         dx1_16 = r[3] if bf else dx1
         dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
         # ---- attention
         do = p_dgrad(dx1_16, wo_c, act_dtype)
-        dwo = p_wgrad(dx1_16, o) if need[5] else None
+        dwo = on_side(lambda: p_wgrad(dx1_16, o)) if need[5] else None
         dqkv = _empty((M, 3 * D), act_dtype, g)
         s3 = (T * 3 * D, 3 * D)
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
                         0, D, 2 * D)
         p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D)
         dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
-        dwqkv = p_wgrad(dqkv, y1) if need[3] else None
-        dbqkv = p_colsum(dqkv) if need[4] else None
+        dwqkv = on_side(lambda: p_wgrad(dqkv, y1)) if need[3] else None
+        dbqkv = on_side(lambda: p_colsum(dqkv)) if need[4] else None
         r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
         dx, dln1w, dln1b = r[0], r[1], r[2]
         dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
+        if side is not None:
+            main.wait_stream(side)  # every buffer the side stream read may be recycled after this point
         dx = dx.view(B, T, D)
         if bf:
             dx._segclip_bf16 = r[3].view(B, T, D)
