@@ -242,6 +242,69 @@ int segclip_reduce_sum(const float* x, float* out, int64_t n, float scale, void*
 int segclip_mask_sort(const float* noise, int64_t* ids_shuffle, int64_t* ids_restore, float* mask,
                       int64_t B, int64_t L, int64_t len_keep, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-step tail with no host synchronisation:
+ *   torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad)      main_task_align.py:326
+ *   AdaptAdamW.step()                                                   modules/optimization_adamw.py:111-174
+ *   "skip the loss with NAN manually"                                   main_task_align.py:331-339
+ *   torch.clamp_(logit_scale, max=ln 100), total_loss += float(loss)    main_task_align.py:323, 343-347
+ * All tensors fp32 (the master copy); `shadow_bf16`, when non-NULL, receives the bf16 rounding of
+ * the updated parameter (the compute-dtype copy the next forward's GEMMs read).
+ *
+ * One segclip_train_ctrl lives in device memory, zeroed once by the caller.  A NaN loss makes
+ * segclip_adamw_step leave param/exp_avg/exp_avg_sq untouched and segclip_train_step_finish count
+ * the skip; the bias corrections and the schedule use  step = tensor.step - ctrl->nan_skips, i.e.
+ * exactly the reference's state['step'] (which is not advanced on skipped iterations).
+ * ------------------------------------------------------------------------------------------ */
+enum { SEGCLIP_SCHED_WARMUP_COSINE = 0, SEGCLIP_SCHED_WARMUP_CONSTANT = 1, SEGCLIP_SCHED_WARMUP_LINEAR = 2 };
+
+typedef struct segclip_train_ctrl {
+  float grad_sqnorm; /* sum of squares of all gradients (segclip_grad_sqnorm) */
+  float clip_coef;   /* min(1, max_norm / (sqrt(grad_sqnorm) + 1e-6)) */
+  int32_t nan_skips; /* iterations skipped so far because the loss was NaN */
+  int32_t steps;     /* iterations finished (skipped ones included) */
+  float loss_sum;    /* running sum of the non-NaN losses (train_epoch's total_loss) */
+  float last_loss;
+  int32_t reserved[2];
+} segclip_train_ctrl;
+
+typedef struct segclip_adamw_group { /* one torch param_group: optimization_adamw.py:70-73 */
+  double lr, weight_decay, b1, b2, eps, warmup, lr_start, lr_end;
+  int64_t t_total;  /* -1: constant lr */
+  int32_t schedule; /* SEGCLIP_SCHED_* */
+  int32_t reserved;
+} segclip_adamw_group;
+
+typedef struct segclip_adamw_tensor {
+  float* param;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  void* shadow_bf16; /* nullable */
+  int64_t n;
+  int32_t step;  /* host-side count of steps (this one included) in which this tensor had a grad */
+  int32_t group; /* index into groups[] */
+} segclip_adamw_tensor;
+
+/* number of fp32 partial sums segclip_grad_sqnorm needs in `ws` for these tensor sizes */
+size_t segclip_grad_sqnorm_ws_bytes(const int64_t* n, int64_t count);
+/* ctrl->grad_sqnorm = sum_i |grads[i]|^2 (deterministic two-level reduction), ctrl->clip_coef as above
+ * (max_norm <= 0: coef = 1).  grads/n are HOST arrays of device pointers / element counts. */
+int segclip_grad_sqnorm(const float* const* grads, const int64_t* n, int64_t count, float* ws,
+                        segclip_train_ctrl* ctrl, float max_norm, void* stream);
+/* fused multi-tensor AdaptAdamW step.  tensors/groups are HOST arrays (passed to the kernels by
+ * value, 32 tensors per launch).  g = grad * ctrl->clip_coef; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g g;
+ * denom = sqrt(v)/sqrt(1-b2^step) + eps; p = p (1 - lr_t wd) - (lr_t/(1-b1^step)) m/denom, where
+ * lr_t = lr * schedule(step/t_total).  ctrl may be NULL (coef 1, no NaN logic, step = tensor.step);
+ * loss may be NULL.  zero_grads != 0 also clears every grad (even on a skipped iteration). */
+int segclip_adamw_step(const segclip_adamw_tensor* tensors, int64_t count, const segclip_adamw_group* groups,
+                       int64_t ngroups, const segclip_train_ctrl* ctrl, const float* loss, int zero_grads,
+                       void* stream);
+/* bookkeeping after the step: ctrl->nan_skips += isnan(*loss); ctrl->steps++; loss_sum/last_loss;
+ * *logit_scale = min(*logit_scale, clamp_max) when logit_scale != NULL. */
+int segclip_train_step_finish(segclip_train_ctrl* ctrl, const float* loss, float* logit_scale, float clamp_max,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif
