@@ -29,6 +29,22 @@ class GemmDesc(C.Structure):
                 ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp)]
 
 
+class TrainCtrl(C.Structure):
+    _fields_ = [("grad_sqnorm", f32), ("clip_coef", f32), ("nan_skips", i32), ("steps", i32),
+                ("loss_sum", f32), ("last_loss", f32), ("reserved", i32 * 2)]
+
+
+class AdamWGroup(C.Structure):
+    _fields_ = [("lr", C.c_double), ("weight_decay", C.c_double), ("b1", C.c_double), ("b2", C.c_double),
+                ("eps", C.c_double), ("warmup", C.c_double), ("lr_start", C.c_double), ("lr_end", C.c_double),
+                ("t_total", i64), ("schedule", i32), ("reserved", i32)]
+
+
+class AdamWTensor(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("shadow_bf16", vp),
+                ("n", i64), ("step", i32), ("group", i32)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("stats", vp), ("dO", vp), ("dQ", vp), ("dK", vp),
                 ("dV", vp), ("ws", vp),
@@ -77,6 +93,10 @@ SIGNATURES = {
     "segclip_masked_mse_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_masked_mse_bwd": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_mask_sort": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_grad_sqnorm_ws_bytes": (C.c_size_t, [vp, i64]),
+    "segclip_grad_sqnorm": (C.c_int, [vp, vp, i64, vp, vp, f32, vp]),
+    "segclip_adamw_step": (C.c_int, [vp, i64, vp, i64, vp, vp, C.c_int, vp]),
+    "segclip_train_step_finish": (C.c_int, [vp, vp, vp, f32, vp]),
 }
 
 

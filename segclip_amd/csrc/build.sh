@@ -7,7 +7,7 @@ OUT=../libsegclip_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 mkdir -p build
 pids=()
-for f in gemm_f32.hip gemm_bf16.hip gemm_bf16_dma.hip layernorm.hip attention.hip misc.hip; do
+for f in gemm_f32.hip gemm_bf16.hip gemm_bf16_dma.hip layernorm.hip attention.hip misc.hip optim.hip; do
   $HIPCC $FLAGS -c $f -o build/${f%.hip}.o &
   pids+=($!)
 done

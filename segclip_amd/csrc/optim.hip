@@ -154,19 +154,19 @@ __global__ __launch_bounds__(kThreads) void adamw_step_kernel(StepLaunch L, Grou
     pp = pp * s.decay - s.step_size * (mm / denom);
   };
   for (int64_t i = threadIdx.x; i < nv; i += kThreads) {
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
-    upd(pp.x, gg.x, mm.x, vv.x);
-    upd(pp.y, gg.y, mm.y, vv.y);
-    upd(pp.z, gg.z, mm.z, vv.z);
-    upd(pp.w, gg.w, mm.w, vv.w);
-    reinterpret_cast<f32x4*>(p)[i] = pp;
-    reinterpret_cast<f32x4*>(m)[i] = mm;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
+    const f32x4 p4 = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+    const f32x4 m4 = reinterpret_cast<f32x4*>(m)[i];
+    const f32x4 v4 = reinterpret_cast<f32x4*>(v)[i];
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) upd(pp[e], gg[e], mm[e], vv[e]);
+    reinterpret_cast<f32x4*>(p)[i] = f32x4{pp[0], pp[1], pp[2], pp[3]};
+    reinterpret_cast<f32x4*>(m)[i] = f32x4{mm[0], mm[1], mm[2], mm[3]};
+    reinterpret_cast<f32x4*>(v)[i] = f32x4{vv[0], vv[1], vv[2], vv[3]};
     if (L.zero_grads) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (sh) reinterpret_cast<u32x2*>(sh)[i] = u32x2{pack2bf(pp.x, pp.y), pack2bf(pp.z, pp.w)};
+    if (sh) reinterpret_cast<u32x2*>(sh)[i] = u32x2{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3])};
   }
   for (int64_t i = (nv << 2) + threadIdx.x; i < left; i += kThreads) {
     float pp = p[i], mm = m[i], vv = v[i];
@@ -229,7 +229,7 @@ extern "C" int segclip_grad_sqnorm(const float* const* grads, const int64_t* n, 
   }
   hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(kThreads), 0, st, ws, (int)total_blocks, ctrl, max_norm);
   SEGCLIP_CHECK_LAUNCH("segclip_grad_sqnorm");
-  return SEGCLIP_OK;
+  return 0;
 }
 
 extern "C" int segclip_adamw_step(const segclip_adamw_tensor* tensors, int64_t count, const segclip_adamw_group* groups,
@@ -271,7 +271,7 @@ extern "C" int segclip_adamw_step(const segclip_adamw_tensor* tensors, int64_t c
     hipLaunchKernelGGL(adamw_step_kernel, dim3(nb), dim3(kThreads), 0, st, L, G, ctrl, loss);
   }
   SEGCLIP_CHECK_LAUNCH("segclip_adamw_step");
-  return SEGCLIP_OK;
+  return 0;
 }
 
 extern "C" int segclip_train_step_finish(segclip_train_ctrl* ctrl, const float* loss, float* logit_scale, float clamp_max,
@@ -279,5 +279,5 @@ extern "C" int segclip_train_step_finish(segclip_train_ctrl* ctrl, const float* 
   SEGCLIP_REQUIRE(ctrl, "segclip_train_step_finish: null ctrl");
   hipLaunchKernelGGL(train_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctrl, loss, logit_scale, clamp_max);
   SEGCLIP_CHECK_LAUNCH("segclip_train_step_finish");
-  return SEGCLIP_OK;
+  return 0;
 }
