@@ -144,6 +144,8 @@ __global__ __launch_bounds__(kThreads) void adamw_step_kernel(StepLaunch L, Grou
       for (int64_t i = threadIdx.x; i < nv; i += kThreads) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int64_t i = (nv << 2) + threadIdx.x; i < left; i += kThreads) g[i] = 0.f;
     }
+    if (sh)  // keep the shadow consistent with the (unchanged) parameter even on the very first iteration
+      for (int64_t i = threadIdx.x; i < left; i += kThreads) sh[i] = f2bf(p[i]);
     return;
   }
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {

@@ -261,7 +261,13 @@ def _wgrad_stream():
 
 
 def wcast(w, act_dtype):
-    """Parameter (fp32 master) in the compute dtype of the current mode."""
+    """Parameter (fp32 master) in the compute dtype of the current mode.  When the fused optimizer maintains a
+    bf16 shadow (modules/optimization_adamw.py, shadow_bf16=True) and nothing else has written the parameter
+    since (same autograd version), the shadow is used instead of casting again."""
+    if act_dtype == torch.bfloat16:
+        sh = getattr(w, "_segclip_shadow", None)
+        if sh is not None and sh[1] == w._version and sh[0].shape == w.shape:
+            return sh[0]
     return p_cast(w.detach(), act_dtype)
 
 
