@@ -132,6 +132,10 @@ typedef struct segclip_attn_desc {
   int32_t causal;
   int32_t dtype;
   int32_t reserved;
+  /* bwd, bf16 only, nullable: fp32 [B][3][H*hd] receives, per sample, the token sums of dQ | dK | dV
+   * (= that sample's contribution to the in_proj bias gradient of nn.MultiheadAttention), computed from the
+   * tiles already in LDS instead of a separate column-sum pass over dQ/dK/dV. */
+  void* colsum_part;
 } segclip_attn_desc;
 
 size_t segclip_attn_stats_bytes(const segclip_attn_desc* d);
@@ -285,6 +289,10 @@ typedef struct segclip_adamw_tensor {
   int32_t step;  /* host-side count of steps (this one included) in which this tensor had a grad */
   int32_t group; /* index into groups[] */
 } segclip_adamw_tensor;
+
+/* dst[i][:] = bf16(src[i][:]) for `count` fp32 tensors in ceil(count/32) launches (the compute-dtype copies of the
+ * GEMM weights, refreshed once per forward instead of one cast launch per weight).  src/dst/n are HOST arrays. */
+int segclip_multi_cast_bf16(const float* const* src, void* const* dst, const int64_t* n, int64_t count, void* stream);
 
 /* number of fp32 partial sums segclip_grad_sqnorm needs in `ws` for these tensor sizes */
 size_t segclip_grad_sqnorm_ws_bytes(const int64_t* n, int64_t count);

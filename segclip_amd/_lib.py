@@ -53,7 +53,7 @@ class AttnDesc(C.Structure):
                 ("o_sb", i64), ("o_st", i64),
                 ("dq_sb", i64), ("dq_st", i64), ("dk_sb", i64), ("dk_st", i64), ("dv_sb", i64), ("dv_st", i64),
                 ("do_sb", i64), ("do_st", i64),
-                ("scale", f32), ("causal", i32), ("dtype", i32), ("reserved", i32)]
+                ("scale", f32), ("causal", i32), ("dtype", i32), ("reserved", i32), ("colsum_part", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/segclip_hip.h
@@ -93,6 +93,7 @@ SIGNATURES = {
     "segclip_masked_mse_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_masked_mse_bwd": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_mask_sort": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_multi_cast_bf16": (C.c_int, [vp, vp, vp, i64, vp]),
     "segclip_grad_sqnorm_ws_bytes": (C.c_size_t, [vp, i64]),
     "segclip_grad_sqnorm": (C.c_int, [vp, vp, i64, vp, vp, f32, vp]),
     "segclip_adamw_step": (C.c_int, [vp, i64, vp, i64, vp, vp, C.c_int, vp]),

@@ -17,6 +17,9 @@ cross_mode = "t18"
 overlap_wgrad = False  # weight-gradient GEMMs of a block on a second HIP stream; measured SLOWER (64.4 vs 59.5 ms/step:
                        # two 139-KiB-LDS GEMMs cannot share a CU and the interleaving delays the dgrad chain), kept off
 overlap_towers = True  # enqueue the text tower on a second HIP stream (concurrent with the vision tower)
+trust_weight_shadows = False  # False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
+                              # True: only weights whose autograd version changed (set by train.prep_optimizer when the
+                              # fused optimizer maintains the bf16 copies itself)
 _noise = None
 
 

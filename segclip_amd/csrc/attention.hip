@@ -193,9 +193,12 @@ struct BwdArgs {
   int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, do_sb, do_st;
   int64_t dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
   float scale; int causal;
+  float* colsum_part;  // nullable: [B][3][H*hd] token sums of dQ | dK | dV (the in_proj bias gradient, per sample)
 };
 
 constexpr int TMAX = 256;
+// LDS bytes of the backward kernel for tiles of tp (padded) rows: Q,K,V,dO tiles + lse,D,cs,rs vectors + reduce pad
+static inline size_t bwd_lds_bytes(int tp) { return (size_t)tp * (4 * ROWB + 4 * 4) + 8 * 3 * 64 * 4; }
 
 __device__ __forceinline__ void store_acc_T(bf16_t* base, int64_t st, int row, int nrows, int hd, const f32x16 (&acc)[2],
                                             int lh) {
@@ -216,13 +219,19 @@ __device__ __forceinline__ void store_acc_T(bf16_t* base, int64_t st, int row, i
 }
 
 __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TMAX * ROWB + 2 * TMAX * 4];
-  char* Qt = smem;
-  char* Kt = smem + TMAX * ROWB;
-  char* Vt = smem + 2 * TMAX * ROWB;
-  char* Gt = smem + 3 * TMAX * ROWB;  // dO
-  float* Ls = reinterpret_cast<float*>(smem + 4 * TMAX * ROWB);
-  float* Ds = Ls + TMAX;
+  // dynamic LDS sized by the padded sequence length: a 77-token text head needs 57 KB (two workgroups per CU)
+  // instead of the 133 KB of a 256-row allocation
+  extern __shared__ __attribute__((aligned(16))) char smem_bwd[];
+  const int tp0 = (((a.Tq > a.Tk ? a.Tq : a.Tk) + 31) & ~31);
+  char* Qt = smem_bwd;
+  char* Kt = smem_bwd + tp0 * ROWB;
+  char* Vt = smem_bwd + 2 * tp0 * ROWB;
+  char* Gt = smem_bwd + 3 * tp0 * ROWB;  // dO
+  float* Ls = reinterpret_cast<float*>(smem_bwd + 4 * tp0 * ROWB);
+  float* Ds = Ls + tp0;
+  float* Cs = Ds + tp0;   // cs[key] = sum_q dS[q][key]
+  float* Rs = Cs + tp0;   // rs[q]   = sum_key dS[q][key]
+  float* Red = Rs + tp0;  // [8 waves][3][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int li = lane & 31, lh = lane >> 5;
@@ -286,6 +295,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
     const int key = k0 + li;
+    float csl = 0.f;
     for (int q0 = 0; q0 < tqp; q0 += 32) {
       if (a.causal && q0 + 31 < k0) continue;
       f32x16 s, dp;
@@ -309,6 +319,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
           const float pv = ok ? __expf(s[r] * a.scale - l4[j]) : 0.f;
           p[r] = pv;
           ds[r] = pv * (dp[r] - d4[j]) * a.scale;
+          csl += ds[r];
         }
       }
       const bf16x8_t pb0 = pack8(p), pb1 = pack8(p + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
@@ -322,6 +333,8 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
     }
     store_acc_T(a.dK + b * a.dk_sb + hoff, a.dk_st, key, a.Tk, a.hd, dk, lh);
     store_acc_T(a.dV + b * a.dv_sb + hoff, a.dv_st, key, a.Tk, a.hd, dv, lh);
+    csl += __shfl_xor(csl, 32, 64);
+    if (lh == 0) Cs[key] = csl;
   }
 
   // ---------------- pass B: this wave owns query tiles; dQ ----------------
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
     const int q = q0 + li;
     const float lq = Ls[q], dq_ = Ds[q];
     f32x16 dq[2];
+    float rsl = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
     for (int k0 = 0; k0 < tkp; k0 += 32) {
@@ -351,6 +365,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
         const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
         const float pv = ok ? __expf(s[r] * a.scale - lq) : 0.f;
         ds[r] = pv * (dp[r] - dq_) * a.scale;
+        rsl += ds[r];
       }
       const bf16x8_t sb0 = pack8(ds), sb1 = pack8(ds + 8);
 #pragma unroll
@@ -360,6 +375,63 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
       }
     }
     store_acc_T(a.dQ + b * a.dq_sb + hoff, a.dq_st, q, a.Tq, a.hd, dq, lh);
+    rsl += __shfl_xor(rsl, 32, 64);
+    if (lh == 0) Rs[q] = rsl;
+  }
+
+  // ---------------- token sums of dQ, dK, dV from the tiles still in LDS (in_proj bias gradient) ----------------
+  //   sum_q dQ[q][d] = sum_key K[key][d] cs[key];  sum_key dK[key][d] = sum_q Q[q][d] rs[q]  (zero up to rounding:
+  //   softmax is shift invariant);  sum_key dV[key][d] = sum_q dO[q][d]  (the rows of P sum to one).
+  if (a.colsum_part) {
+    __syncthreads();
+    const int c = tid & 7, nrl = (int)blockDim.x >> 3;
+    float acc[3][8];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+    const int tmax = tqp > tkp ? tqp : tkp;
+    for (int r = tid >> 3; r < tmax; r += nrl) {
+      const int off = swz(r, c * 8);
+      if (r < tkp) {
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(Kt + off);
+        const float w = Cs[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][2 * j] += w * __uint_as_float(kv[j] << 16);
+          acc[0][2 * j + 1] += w * __uint_as_float(kv[j] & 0xffff0000u);
+        }
+      }
+      if (r < tqp) {
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(Qt + off);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(Gt + off);
+        const float w = Rs[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[1][2 * j] += w * __uint_as_float(qv[j] << 16);
+          acc[1][2 * j + 1] += w * __uint_as_float(qv[j] & 0xffff0000u);
+          acc[2][2 * j] += __uint_as_float(gv[j] << 16);
+          acc[2][2 * j + 1] += __uint_as_float(gv[j] & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = acc[m][j];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 8) Red[(wave * 3 + m) * 64 + c * 8 + j] = v;
+      }
+    __syncthreads();
+    for (int t = tid; t < 192; t += (int)blockDim.x) {
+      const int m = t >> 6, dd = t & 63;
+      float v = 0.f;
+      for (int w = 0; w < nw; ++w) v += Red[(w * 3 + m) * 64 + dd];
+      if (dd < a.hd) a.colsum_part[((int64_t)b * 3 + m) * ((int64_t)a.H * a.hd) + hoff + dd] = v;
+    }
   }
 }
 
@@ -483,10 +555,21 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.scale = d->scale; a.causal = d->causal;
     const int tiles = (int)cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32);
     const int nw = tiles < 8 ? tiles : 8;
-    hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(d->B * d->H)), dim3(nw * 64), 0, stream, a);
+    a.colsum_part = (float*)d->colsum_part;
+    const int tp = (int)(cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32) * 32);
+    const size_t lds = bwd_lds_bytes(tp);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes(TMAX));
+      SEGCLIP_REQUIRE(e == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(d->B * d->H)), dim3(nw * 64), lds, stream, a);
     SEGCLIP_CHECK_LAUNCH("attn_bwd_bf16");
     return 0;
   }
+  SEGCLIP_REQUIRE(d->colsum_part == nullptr, "attn_bwd f32: colsum_part is a bf16-path feature");
   SEGCLIP_REQUIRE(d->ws != nullptr, "attn_bwd f32: workspace required");
   const float* P = (const float*)d->stats;
   float* dP = (float*)d->ws;

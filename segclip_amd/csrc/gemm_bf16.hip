@@ -18,6 +18,7 @@
 // load).  Workgroup ids are remapped so each XCD walks a contiguous run of tiles (A panel reuse in its L2).
 // Split-K (grid.y) for the wgrad shapes, combined by a deterministic slab reduction.
 #include "gemm_bf16_common.h"
+#include "reduce_rows.h"
 
 namespace {
 
@@ -293,23 +294,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, in
   }
 }
 
-// out[c] = sum_r part[r][c]; block = 64 columns x 16 row lanes (deterministic)
-__global__ __launch_bounds__(1024) void colsum_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                 int64_t rows, int64_t N) {
-  __shared__ float red[16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < N)
-    for (int64_t r = rl; r < rows; r += 16) s += part[r * N + c];
-  red[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && c < N) {
-    float t = 0.f;
+// contiguous fp32/bf16 C (ldc == N, one batch): 16-byte loads, four slabs in flight, no index arithmetic
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ slab, void* __restrict__ C,
+                                                                int64_t total4, int splits, float alpha, int c_dtype) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(slab) + i;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+#pragma unroll 1
+  for (; s + 8 <= splits; s += 8) {
+    f32x4 t[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][cl];
-    out[c] = t;
+    for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(s + u) * total4];
+    v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   }
+  if (s + 4 <= splits) {
+    const f32x4 a = p[(int64_t)s * total4], b = p[(int64_t)(s + 1) * total4], c = p[(int64_t)(s + 2) * total4],
+                d = p[(int64_t)(s + 3) * total4];
+    v += (a + b) + (c + d);
+    s += 4;
+  }
+  for (; s < splits; ++s) v += p[(int64_t)s * total4];
+  v *= alpha;
+  if (c_dtype == SEGCLIP_BF16)
+    reinterpret_cast<u32x2*>(C)[i] = u32x2{pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+  else
+    reinterpret_cast<f32x4*>(C)[i] = v;
 }
 
 }  // namespace
@@ -419,14 +430,19 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   }
   SEGCLIP_CHECK_LAUNCH("gemm_bf16");
   if (d->colsum) {
-    hipLaunchKernelGGL(colsum_part_reduce_kernel, dim3((unsigned)cdiv(d->N, 64)), dim3(1024), 0, stream,
-                       (const float*)d->colsum_ws, d->colsum, d->M / 64, d->N);
+    launch_reduce_rows((const float*)d->colsum_ws, d->M / 64, d->N, d->N, d->colsum, nullptr, nullptr, d->N, stream);
     SEGCLIP_CHECK_LAUNCH("gemm_colsum_reduce");
   }
   if (g.splits > 1) {
     const int64_t total = nb * d->M * d->N;
     const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->ws, d->C, d->M,
+    const int64_t cal = d->c_dtype == SEGCLIP_BF16 ? 7 : 15;
+    if (nb == 1 && d->ldc == d->N && total % 4 == 0 && (reinterpret_cast<uintptr_t>(d->C) & cal) == 0 &&
+        (reinterpret_cast<uintptr_t>(d->ws) & 15) == 0)
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)cdiv(total / 4, 256)), dim3(256), 0, stream,
+                         (const float*)d->ws, d->C, total / 4, g.splits, d->alpha, d->c_dtype);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->ws, d->C, d->M,
                        d->N, d->ldc, g.nb2, d->bsC1, d->bsC2, g.splits, nb, d->alpha, d->c_dtype);
     SEGCLIP_CHECK_LAUNCH("splitk_reduce");
   }

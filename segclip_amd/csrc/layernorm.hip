@@ -3,6 +3,7 @@
 // two reductions.  Backward fuses the residual-gradient add (dx = LN'(dy) + dres) and produces
 // dgamma/dbeta through a deterministic two-stage reduction (per-block partials -> column sums).
 #include "common.h"
+#include "reduce_rows.h"
 
 namespace {
 
@@ -157,27 +158,6 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
   }
 }
 
-// out[c] = sum_b part[b][c] over the 3*cols columns (dgamma | dbeta | colsum(dres)); 64 columns x 16 row lanes
-__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                                          float* __restrict__ out1, float* __restrict__ out2, int nb,
-                                                          int cols) {
-  __shared__ float red[16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int width = out2 ? 3 * cols : 2 * cols;
-  float s = 0.f;
-  if (c < width)
-    for (int b = rl; b < nb; b += 16) s += part[(int64_t)b * 3 * cols + c];
-  red[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && c < width) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][cl];
-    if (c < cols) out0[c] = t; else if (c < 2 * cols) out1[c - cols] = t; else out2[c - 2 * cols] = t;
-  }
-}
-
 int ln_blocks(int64_t rows) {
   int64_t b = cdiv(rows, WAVES);
   return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
@@ -224,8 +204,8 @@ extern "C" int segclip_layernorm_bwd(const void* dy, const void* x, const float*
   }
 #undef LNB
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)cdiv(3 * cols, 64)), dim3(1024), 0, (hipStream_t)stream,
-                     (const float*)ws, dgamma, dbeta, dres ? dres_colsum : nullptr, nb, (int)cols);
+  launch_reduce_rows((const float*)ws, nb, (dres && dres_colsum ? 3 : 2) * cols, 3 * cols, dgamma, dbeta,
+                     dres ? dres_colsum : nullptr, cols, (hipStream_t)stream);
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd_reduce");
   return 0;
 }

@@ -2,6 +2,7 @@
 // activations, vision/text front ends, row gathers, learnable-center hard assignment, losses and the
 // MAE masking sort.  All integer outputs (argmax, ranks) are computed in fp32/integer arithmetic only.
 #include "common.h"
+#include "reduce_rows.h"
 
 namespace {
 
@@ -459,12 +460,21 @@ extern "C" size_t segclip_colsum_ws_bytes(int64_t M, int64_t N) { return (size_t
 extern "C" int segclip_colsum(const void* X, float* out, void* ws, int64_t M, int64_t N, int64_t ld, int dt, void* stream) {
   SEGCLIP_REQUIRE(ws != nullptr, "colsum: workspace required");
   if (N == 0) return 0;
+  // a short fp32 matrix (per-sample partial sums): one pass of the row-reduce kernel, no partial stage
+  if (dt == SEGCLIP_F32 && M <= 4096 && N % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    launch_reduce_rows((const float*)X, M, N, ld, out, nullptr, nullptr, N, ST);
+    SEGCLIP_CHECK_LAUNCH("colsum_rows");
+    return 0;
+  }
   const int64_t nchunk = colsum_chunks(M);
   const int64_t rows_per = cdiv(M > 0 ? M : 1, nchunk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(N, 256), (unsigned)nchunk), dim3(256), 0, ST, X, (float*)ws,
                      M, N, ld, dt, rows_per);
   SEGCLIP_CHECK_LAUNCH("colsum_partial");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, ST, (const float*)ws, out, nchunk, N);
+  if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0)
+    launch_reduce_rows((const float*)ws, nchunk, N, N, out, nullptr, nullptr, N, ST);
+  else
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, ST, (const float*)ws, out, nchunk, N);
   SEGCLIP_CHECK_LAUNCH("colsum_final");
   return 0;
 }

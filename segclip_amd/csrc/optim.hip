@@ -194,6 +194,28 @@ __global__ void train_finish_kernel(segclip_train_ctrl* ctrl, const float* loss,
   if (logit_scale) *logit_scale = fminf(*logit_scale, clamp_max);
 }
 
+struct CastLaunch {
+  const float* src[kTensorsPerLaunch];
+  bf16_t* dst[kTensorsPerLaunch];
+  int64_t n[kTensorsPerLaunch];
+  int32_t first_block[kTensorsPerLaunch + 1];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(kThreads) void multi_cast_bf16_kernel(CastLaunch L) {
+  const int t = find_tensor(L.first_block, L.count, blockIdx.x);
+  const int64_t base = (int64_t)(blockIdx.x - L.first_block[t]) * kChunk;
+  const int64_t left = L.n[t] - base < kChunk ? L.n[t] - base : kChunk;
+  const float* __restrict__ src = L.src[t] + base;
+  bf16_t* __restrict__ dst = L.dst[t] + base;
+  const int64_t nv = left >> 2;
+  for (int64_t i = threadIdx.x; i < nv; i += kThreads) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(src)[i];
+    reinterpret_cast<u32x2*>(dst)[i] = u32x2{pack2bf(x.x, x.y), pack2bf(x.z, x.w)};
+  }
+  for (int64_t i = (nv << 2) + threadIdx.x; i < left; i += kThreads) dst[i] = f2bf(src[i]);
+}
+
 int64_t blocks_of(int64_t n) { return cdiv(n, kChunk); }
 
 }  // namespace
@@ -281,5 +303,34 @@ extern "C" int segclip_train_step_finish(segclip_train_ctrl* ctrl, const float* 
   SEGCLIP_REQUIRE(ctrl, "segclip_train_step_finish: null ctrl");
   hipLaunchKernelGGL(train_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctrl, loss, logit_scale, clamp_max);
   SEGCLIP_CHECK_LAUNCH("segclip_train_step_finish");
+  return 0;
+}
+
+extern "C" int segclip_multi_cast_bf16(const float* const* src, void* const* dst, const int64_t* n, int64_t count,
+                                       void* stream) {
+  SEGCLIP_REQUIRE(count == 0 || (src && dst && n), "segclip_multi_cast_bf16: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i0 = 0; i0 < count;) {
+    CastLaunch L;
+    int c = 0;
+    int32_t nb = 0;
+    for (; i0 < count && c < kTensorsPerLaunch; ++i0) {
+      if (n[i0] <= 0) continue;
+      SEGCLIP_REQUIRE(src[i0] && dst[i0], "segclip_multi_cast_bf16: null pointer in tensor %lld", (long long)i0);
+      SEGCLIP_REQUIRE(((uintptr_t)src[i0] & 15) == 0 && ((uintptr_t)dst[i0] & 7) == 0,
+                      "segclip_multi_cast_bf16: tensor %lld is not aligned", (long long)i0);
+      L.src[c] = src[i0];
+      L.dst[c] = (bf16_t*)dst[i0];
+      L.n[c] = n[i0];
+      L.first_block[c] = nb;
+      nb += (int32_t)blocks_of(n[i0]);
+      ++c;
+    }
+    if (c == 0) continue;
+    for (int j = c; j <= kTensorsPerLaunch; ++j) L.first_block[j] = nb;
+    L.count = c;
+    hipLaunchKernelGGL(multi_cast_bf16_kernel, dim3(nb), dim3(kThreads), 0, st, L);
+  }
+  SEGCLIP_CHECK_LAUNCH("segclip_multi_cast_bf16");
   return 0;
 }

@@ -127,6 +127,8 @@ class SegCLIP(SegCLIPPreTrainedModel):
         image_frame = 1
         if not self.training:
             return None
+        if config.compute_dtype == torch.bfloat16:
+            ops.refresh_weight_shadows(force=not config.trust_weight_shadows)
         # The two towers are independent until the similarity: the text tower (small GEMMs that leave most CUs
         # idle) is enqueued on a second HIP stream so its kernels fill the gaps of the vision tower; autograd runs
         # each node's backward on the stream of its forward, so the overlap carries over to the backward pass.

@@ -10,6 +10,7 @@ path (fp32 residual stream, fp32 parameters / parameter gradients in both modes)
 """
 import ctypes as C
 import math
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -235,9 +236,11 @@ def p_attn_fwd(d, like):
     return stats
 
 
-def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0, dv_off=0):
+def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0, dv_off=0, colsum_part=None):
+    """colsum_part (bf16 path only): fp32 (B, 3*H*hd) buffer that receives the per-sample token sums of dQ|dK|dV."""
     lib = L.load()
     d.stats = L.ptr(stats)
+    d.colsum_part = L.ptr(colsum_part)
     d.dO, d.dQ, d.dK, d.dV = L.ptr(do), _off(dq, dq_off), _off(dk, dk_off), _off(dv, dv_off)
     d.dq_sb, d.dq_st = dqs
     d.dk_sb, d.dk_st = dks
@@ -260,15 +263,60 @@ def _wgrad_stream():
     return st
 
 
+_WCAST_PARAMS = {}  # id -> weakref of every Parameter that went through wcast (the GEMM weights)
+
+
 def wcast(w, act_dtype):
-    """Parameter (fp32 master) in the compute dtype of the current mode.  When the fused optimizer maintains a
-    bf16 shadow (modules/optimization_adamw.py, shadow_bf16=True) and nothing else has written the parameter
-    since (same autograd version), the shadow is used instead of casting again."""
+    """Parameter (fp32 master) in the compute dtype of the current mode.
+
+    bf16 copies ("shadows") live on the Parameter object as `_segclip_shadow = [tensor, version]` and are valid while
+    the parameter's autograd version is unchanged.  They are written either by refresh_weight_shadows() (one
+    multi-tensor cast at the start of a forward) or by the fused optimizer together with the parameter itself
+    (modules/optimization_adamw.py, shadow_bf16=True).  A miss casts on the spot and registers the parameter."""
     if act_dtype == torch.bfloat16:
         sh = getattr(w, "_segclip_shadow", None)
         if sh is not None and sh[1] == w._version and sh[0].shape == w.shape:
             return sh[0]
+        if isinstance(w, torch.nn.Parameter) and w.is_contiguous():
+            buf = sh[0] if (sh is not None and sh[0].shape == w.shape) else torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+            p_cast_into(w.detach(), buf)
+            w._segclip_shadow = [buf, w._version]
+            _WCAST_PARAMS[id(w)] = weakref.ref(w)
+            return buf
     return p_cast(w.detach(), act_dtype)
+
+
+def p_cast_into(x, out):
+    lib = L.load()
+    L.check(lib.segclip_cast(L.ptr(x), L.ptr(out), x.numel(), L.dt(x), L.dt(out), L.stream()), "cast")
+    return out
+
+
+def refresh_weight_shadows(force=True):
+    """Re-cast every registered GEMM weight in ceil(T/32) launches.  force=False trusts shadows whose version
+    still matches (what the fused optimizer guarantees); force=True is the conservative per-forward behaviour."""
+    todo = []
+    for key, ref in list(_WCAST_PARAMS.items()):
+        w = ref()
+        if w is None:
+            del _WCAST_PARAMS[key]
+            continue
+        sh = getattr(w, "_segclip_shadow", None)
+        if sh is None or not w.is_cuda:
+            continue
+        if force or sh[1] != w._version:
+            todo.append((w, sh))
+    if not todo:
+        return 0
+    n = len(todo)
+    src = (C.c_void_p * n)(*[w.data_ptr() for w, _ in todo])
+    dst = (C.c_void_p * n)(*[sh[0].data_ptr() for _, sh in todo])
+    cnt = (C.c_int64 * n)(*[w.numel() for w, _ in todo])
+    L.check(L.load().segclip_multi_cast_bf16(C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p), C.cast(cnt, C.c_void_p), n,
+                                             L.stream()), "multi_cast_bf16")
+    for w, sh in todo:
+        sh[1] = w._version
+    return n
 
 
 # ------------------------------------------------------------------------------------------------
@@ -487,10 +535,11 @@ class ResBlockFn(Function):
         s3 = (T * 3 * D, 3 * D)
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
                         0, D, 2 * D)
-        p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D)
+        part = _empty((B, 3 * D), torch.float32, g) if (bf and need[4]) else None  # in_proj bias gradient per sample
+        p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
         dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
         dwqkv = on_side(lambda: p_wgrad(dqkv, y1)) if need[3] else None
-        dbqkv = on_side(lambda: p_colsum(dqkv)) if need[4] else None
+        dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv)) if need[4] else None
         r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
         dx, dln1w, dln1b = r[0], r[1], r[2]
         dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward

@@ -110,9 +110,11 @@ def prep_optimizer(args, model, num_train_optimization_steps, device=None, n_gpu
         if lrs[gi] is not None:
             g['lr'] = lrs[gi]
         groups.append(g)
+    from . import config
     if shadow_bf16 is None:
-        from . import config
         shadow_bf16 = config.compute_dtype == torch.bfloat16
+    if shadow_bf16:
+        config.trust_weight_shadows = True  # the optimizer kernel rewrites the bf16 copies together with the weights
     optimizer = AdaptAdamW(groups, lr=args.lr, warmup=args.warmup_proportion, schedule='warmup_cosine',
                            b1=args.opt_b1, b2=args.opt_b2, e=args.eps, t_total=num_train_optimization_steps,
                            weight_decay=args.weight_decay, max_grad_norm=1.0,

@@ -176,10 +176,17 @@ def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
     do = rnd(B * T, D, dtype=dtype, seed=42)
     dqkv = torch.zeros(B * T, 3 * D, dtype=dtype, device=DEV)
     d = ops._attn_desc(qkv, qkv, qkv, o, B, H, T, T, hd, s3, s3, s3, (T * D, D), 1 / math.sqrt(hd), causal, 0, D, 2 * D)
-    ops.p_attn_bwd(d, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D)
+    part = torch.full((B, 3 * D), float("nan"), device=DEV) if dtype == BF else None
+    ops.p_attn_bwd(d, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
     ref.backward(do.float().view(B, T, D))
     rt, at = (2e-4, 2e-4) if dtype == F32 else (3e-2, 3e-2)
     close(dqkv.view(B, T, 3, D), qr.grad, rt, at, "attn bwd dqkv")
+    if part is not None:
+        # fused per-sample token sums of dQ|dK|dV (in_proj bias gradient) vs the sums of the exact fp32 gradient
+        want = qr.grad.sum(1).reshape(B, 3 * D)
+        scale = float(qr.grad.abs().sum(1).max())
+        assert float((part - want).abs().max()) <= 6e-3 * scale, (float((part - want).abs().max()), scale)
+        close(part[:, 2 * D:], do.float().view(B, T, D).sum(1), 1e-3, 1e-3, "dv colsum == colsum(dO)")
 
 
 @pytest.mark.parametrize("dtype", [F32, BF])
@@ -406,3 +413,22 @@ def test_mask_sort_bit_exact():
     m = torch.ones(B, Lq, device=DEV)
     m[:, :int(Lq * 0.25)] = 0
     assert torch.equal(mask, torch.gather(m, 1, rr))
+
+
+def test_weight_shadow_registry_and_multi_cast():
+    """ops.wcast keeps one bf16 copy per GEMM weight; refresh_weight_shadows re-casts them in one multi-tensor launch."""
+    ws = [torch.nn.Parameter(rnd(*shape, seed=90 + i)) for i, shape in enumerate([(64, 32), (3, 5), (16385,), (40, 1000)])]
+    copies = [ops.wcast(w, BF) for w in ws]
+    for w, c in zip(ws, copies):
+        assert torch.equal(c, w.detach().to(BF)) and ops.wcast(w, BF) is c
+    ws[0].data.mul_(2.0)                       # raw write: no version bump -> the copy is stale until a forced refresh
+    assert not torch.equal(copies[0], ws[0].detach().to(BF))
+    assert ops.refresh_weight_shadows(force=False) == 0
+    assert ops.refresh_weight_shadows(force=True) >= len(ws)
+    for w, c in zip(ws, copies):
+        assert torch.equal(c, w.detach().to(BF)) and ops.wcast(w, BF) is c
+    with torch.no_grad():
+        ws[1].add_(1.0)                        # torch-side write: version bump -> refreshed without force
+    assert ops.refresh_weight_shadows(force=False) == 1
+    assert torch.equal(copies[1], ws[1].detach().to(BF))
+    assert ops.wcast(ws[2], F32).dtype == F32  # the f32 mode never touches the copies
