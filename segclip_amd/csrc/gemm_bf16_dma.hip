@@ -19,12 +19,13 @@
 // Full tiles leave through the LDS-staged coalesced epilogue (gemm_bf16_common.h).
 // Rows beyond M / N are clamped to valid addresses (their products are never stored); K must be a
 // multiple of 64 (the host falls back to the register-staged kernel otherwise).
+#include <stdlib.h>
+
 #include "gemm_bf16_common.h"
 
 namespace {
 
-constexpr int BM = 256, BK = 64, NT = 512, STAGES = 2;
-constexpr int SZA = BM * BK * 2;  // 32768
+constexpr int BK = 64, STAGES = 2;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -35,10 +36,10 @@ __device__ __forceinline__ void dma16(const bf16_t* src, char* lds_wave_base) {
 }
 
 // k-contiguous operand with ROWS rows: X(row,k) = X[row*ld + k]; [ROWS][128 B]; ROWS/64 pieces per wave.
-template <int ROWS>
+template <int ROWS, int NWV>
 __device__ __forceinline__ void issue_direct(const bf16_t* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows,
                                              int64_t k0, char* lds, int wave, int lane) {
-  constexpr int PER_WAVE = ROWS / 64;
+  constexpr int PER_WAVE = ROWS / (8 * NWV);
 #pragma unroll
   for (int i = 0; i < PER_WAVE; ++i) {
     const int idx = wave * PER_WAVE + i;        // 1-KiB piece = 8 rows of 128 B
@@ -50,10 +51,10 @@ __device__ __forceinline__ void issue_direct(const bf16_t* __restrict__ X, int64
   }
 }
 // k-strided operand with ROWS rows: X(row,k) = X[k*ld + row]; LDS image [64 k][ROWS], k-row = ROWS*2 bytes.
-template <int ROWS>
+template <int ROWS, int NWV>
 __device__ __forceinline__ void issue_ks(const bf16_t* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows,
                                          int64_t k0, char* lds, int wave, int lane) {
-  constexpr int PER_WAVE = ROWS / 64;           // 64 k-rows * ROWS*2 B / 1 KiB / 8 waves
+  constexpr int PER_WAVE = ROWS / (8 * NWV);    // 64 k-rows * ROWS*2 B / 1 KiB / NWV waves
   constexpr int CHUNKS = ROWS / 8;              // 16-B chunks per k-row
 #pragma unroll
   for (int i = 0; i < PER_WAVE; ++i) {
@@ -95,18 +96,25 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-template <bool A_KS, bool B_KS, int BN>
-__global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
+// <BM, BN, NWV>: <256,256,8> and <256,128,8> own a CU (139 KiB of LDS: operand ring / epilogue patches);
+// <128,128,4> (waves 2x2, 64x64 each) needs 68 KiB, so two workgroups share a CU and one's output phase overlaps
+// the other's MFMA phase.
+template <bool A_KS, bool B_KS, int BM, int BN, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kernel(Args g) {
+  constexpr int SZA = BM * BK * 2;
   constexpr int SZB = BN * BK * 2;
   constexpr int SZS = SZA + SZB;
-  constexpr int TM = BN == 256 ? 4 : 2;               // 32-row MFMA tiles per wave along m
+  constexpr int WN = BN / 64;                          // waves along n (64 columns each)
+  constexpr int WM = NWV / WN;                         // waves along m
+  constexpr int TM = BM / (WM * 32);                   // 32-row MFMA tiles per wave along m
   constexpr int WROWS = TM * 32;                       // rows per wave
-  constexpr int LDS_BYTES = STAGES * SZS > 8 * EPI_WAVE_BYTES ? STAGES * SZS : 8 * EPI_WAVE_BYTES;
+  static_assert(TM == 2 || TM == 4, "wave tile must be 64x64 or 128x64");
+  constexpr int LDS_BYTES = STAGES * SZS > NWV * EPI_WAVE_BYTES ? STAGES * SZS : NWV * EPI_WAVE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1);
-  const int wn = BN == 256 ? (wave & 3) : (wave & 1);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -133,16 +141,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
     char* la = smem + (t & 1) * SZS;
     char* lb = la + SZA;
     const int64_t k0 = kbeg + (int64_t)t * BK;
-    if constexpr (A_KS) issue_ks<BM>(A, g.lda, m0, g.M, k0, la, wave, lane);
-    else issue_direct<BM>(A, g.lda, m0, g.M, k0, la, wave, lane);
-    if constexpr (B_KS) issue_ks<BN>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
-    else issue_direct<BN>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
+    if constexpr (A_KS) issue_ks<BM, NWV>(A, g.lda, m0, g.M, k0, la, wave, lane);
+    else issue_direct<BM, NWV>(A, g.lda, m0, g.M, k0, la, wave, lane);
+    if constexpr (B_KS) issue_ks<BN, NWV>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
+    else issue_direct<BN, NWV>(B, g.ldb, n0, g.N, k0, lb, wave, lane);
   };
 
   // The first round of workgroups (one per CU) starts with a bounded, staggered delay: tiles all take the same
   // time, so without it every CU reaches its store phase at the same moment and the HBM write burst (not
   // overlapped with any MFMA: one workgroup per CU) is paid in full by every tile round (+5..10 % measured).
-  if (bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
+  if (NWV == 8 && bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
     const long long t_tile = (long long)nk * 4000 + 20000;
     const long long unit = t_tile / 8 < 5000 ? t_tile / 8 : 5000;
     const long long wait = ((bid >> 3) & 7) * unit;
@@ -170,6 +178,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
     ldfrag(0, fa[0], fb[0]);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
+      // hipcc waits with lgkmcnt(0) at the first MFMA that uses a fragment, i.e. also for whatever was requested
+      // after it.  Consuming chunk kc's registers here puts that wait BEFORE the request of chunk kc+1, whose LDS
+      // latency is then covered by the MFMAs of chunk kc instead of being exposed.
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fa[kc & 1][i])));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[kc & 1][j])));
       if (kc < 3) ldfrag(kc + 1, fa[(kc + 1) & 1], fb[(kc + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (else hipcc re-serialises it)
 #pragma unroll
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_dma_kernel(Args g) {
 
 // tile-count heuristic: the 256x256 tile unless it leaves the 256 CUs badly quantised and 256x128 does not
 static int pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits) {
+  constexpr int BM = 256;
   if (d->N <= 128) return 128;
   auto eff = [&](int bn) {
     const double tiles = (double)cdiv(d->M, BM) * cdiv(d->N, bn) * nbatch_splits;
@@ -255,9 +271,18 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   if (a_ks && (d->M % 8 != 0 || d->M < 8)) return false;
   if (b_ks && (d->N % 8 != 0 || d->N < 8)) return false;
   if (d->M < 64 || d->N < 16) return false;  // tiny problems: the 128x128 kernel wastes less
-  const int bn = pick_bn(d, nb * splits);
+  // 128x128 tiles, 4 waves, 68 KiB of LDS -> two workgroups per CU: the per-tile prologue / output phase of one
+  // overlaps the MFMA phase of the other.  In isolation (tools/bench_gemm.py, MI355X) this wins 10-25 % on the
+  // forward GEMMs with fewer than 4 rounds of 256x256 tiles (N=768 of the vision tower, the whole text tower) and
+  // loses 5-15 % on long-K dgrads and every split-K wgrad; inside the training step (text tower concurrent on a
+  // second stream) a shape-based choice measured 58.4 vs 58.2 ms, i.e. no gain, so the 256-wide tiles stay the
+  // default and SEGCLIP_GEMM_TILE=128 selects this variant for experiments.
+  static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const bool small = force_tile == 128;
+  const int bn = small ? 128 : pick_bn(d, nb * splits);
+  const int bm = small ? 128 : 256;
   g.nbx = (int)cdiv(d->N, bn);
-  g.nby = (int)cdiv(d->M, BM);
+  g.nby = (int)cdiv(d->M, bm);
   g.splits = splits;
   g.kper = kper;
   if (g.colsum_part && bn != 256 && d->N % 128 != 0) return false;
@@ -270,10 +295,11 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
     if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
-#define GO(AK, BKS)                                                                                          \
-  do {                                                                                                       \
-    if (bn == 256) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256>), grid, dim3(NT), 0, stream, g);   \
-    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128>), grid, dim3(NT), 0, stream, g);             \
+#define GO(AK, BKS)                                                                                               \
+  do {                                                                                                            \
+    if (small) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128, 128, 4>), grid, dim3(256), 0, stream, g);   \
+    else if (bn == 256) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 256, 8>), grid, dim3(512), 0, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8>), grid, dim3(512), 0, stream, g);         \
   } while (0)
   if (!a_ks && !b_ks) GO(false, false);
   else if (!a_ks && b_ks) GO(false, true);

@@ -24,7 +24,10 @@ def timeit(fn, reps=10):
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 50176
     rows = []
-    for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    if len(sys.argv) > 2 and sys.argv[2] == "text":
+        shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048)]
+    for (N, K) in shapes:
         x = torch.randn(M, K, device=dev).to(BF)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
         b = torch.randn(N, device=dev)
