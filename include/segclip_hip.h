@@ -238,6 +238,10 @@ int segclip_masked_mse_bwd(const void* pred, const float* target, const float* m
 int segclip_scale(const float* x, const float* s, float* out, int64_t n, void* stream);
 int segclip_reduce_sum(const float* x, float* out, int64_t n, float scale, void* stream);
 
+/* Evaluation tier: positional table at another grid, modules/module_clip_vtransformer.py:35-53 =
+ * F.interpolate(table (n x n x D, channel-last), size=(h, w), mode='bicubic', align_corners=False). */
+int segclip_interp_bicubic(const float* src, float* dst, int64_t n_in, int64_t h, int64_t w, int64_t D, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * MAE random masking (integer path, bit-exact given the noise).  modules/module_clip_util.py:91-124
  * with keep_cls: noise[:,0] = -1; ids_shuffle = argsort(noise) (stable); ids_restore =

@@ -170,14 +170,58 @@ def patch_embed(image, P, patch):
     return cols @ w.t()
 
 
+def interp_pos_embed(pos, h, w):
+    """VisualTransformer.get_pos_embed in eval mode, modules/module_clip_vtransformer.py:35-53: class row kept, the
+    n x n patch rows resampled to h x w with F.interpolate(mode='bicubic', align_corners=False).  The bicubic
+    resampling is restated from its definition (cubic convolution, A = -0.75, source coordinate
+    (dst + 0.5) * n/out - 0.5, taps clamped to the border) in float32 loops over the (small) output grid."""
+    import math
+    import numpy as np
+    tab = pos.detach().numpy().astype(np.float32)
+    n = int(round(math.sqrt(tab.shape[0] - 1)))
+    if h * w == n * n and h == w:
+        return pos
+    D = tab.shape[1]
+    grid = tab[1:].reshape(n, n, D)
+    A = np.float32(-0.75)
+
+    def weights(t):
+        t = np.float32(t)
+        x0, x1, x2, x3 = t + np.float32(1), t, np.float32(1) - t, np.float32(2) - t
+        return [((A * x0 - 5 * A) * x0 + 8 * A) * x0 - 4 * A, ((A + 2) * x1 - (A + 3)) * x1 * x1 + 1,
+                ((A + 2) * x2 - (A + 3)) * x2 * x2 + 1, ((A * x3 - 5 * A) * x3 + 8 * A) * x3 - 4 * A]
+
+    out = np.zeros((h, w, D), np.float32)
+    sy, sx = np.float32(n) / np.float32(h), np.float32(n) / np.float32(w)
+    for oy in range(h):
+        fy = sy * np.float32(oy + 0.5) - np.float32(0.5)
+        iy = int(math.floor(fy))
+        wy = weights(fy - iy)
+        for ox in range(w):
+            fx = sx * np.float32(ox + 0.5) - np.float32(0.5)
+            ix = int(math.floor(fx))
+            wx = weights(fx - ix)
+            acc = np.zeros(D, np.float32)
+            for a in range(4):
+                yy = min(max(iy - 1 + a, 0), n - 1)
+                row = np.zeros(D, np.float32)
+                for b in range(4):
+                    xx = min(max(ix - 1 + b, 0), n - 1)
+                    row += np.float32(wx[b]) * grid[yy, xx]
+                acc += np.float32(wy[a]) * row
+            out[oy, ox] = acc
+    return torch.from_numpy(np.concatenate([tab[:1], out.reshape(h * w, D)], axis=0))
+
+
 # ----------------------------------------------------------------------------------------------
 # towers
 # ----------------------------------------------------------------------------------------------
 def encode_image(image, P, spec, gumbel=None, mask_noise=None, mask_ratio=0.0, cross_mode="t18",
-                 first_stage_layer=10):
+                 first_stage_layer=10, eval_pos_interp=False):
     """CLIP.encode_image(return_hidden=True), modules/module_clip.py:81-103 ->
     VisualTransformer.forward, modules/module_clip_vtransformer.py:55-80 ->
-    SegViT.forward, modules/module_seg_vit.py:403-452.  Training-mode positional table (raw)."""
+    SegViT.forward, modules/module_seg_vit.py:403-452.  Training-mode positional table (raw) unless
+    eval_pos_interp: then the eval-mode table of get_pos_embed (resampled when the patch grid differs)."""
     V = "clip.visual."
     T_ = V + "transformer."
     D = spec["vision_width"]
@@ -185,7 +229,10 @@ def encode_image(image, P, spec, gumbel=None, mask_noise=None, mask_ratio=0.0, c
     x = patch_embed(image, P, spec["patch"])
     B = x.shape[0]
     cls = P[V + "class_embedding"].reshape(1, 1, D).expand(B, 1, D)
-    x = torch.cat([cls, x], dim=1) + P[V + "positional_embedding"]
+    pos = P[V + "positional_embedding"]
+    if eval_pos_interp:
+        pos = interp_pos_embed(pos, image.shape[2] // spec["patch"], image.shape[3] // spec["patch"])
+    x = torch.cat([cls, x], dim=1) + pos
     x = layer_norm(x, P[V + "ln_pre.weight"], P[V + "ln_pre.bias"])
     mae_mask = ids_restore = ids_keep = None
     if mask_ratio > 0:

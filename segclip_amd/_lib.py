@@ -93,6 +93,7 @@ SIGNATURES = {
     "segclip_masked_mse_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_masked_mse_bwd": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_mask_sort": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_interp_bicubic": (C.c_int, [vp, vp, i64, i64, i64, i64, vp]),
     "segclip_multi_cast_bf16": (C.c_int, [vp, vp, vp, i64, vp]),
     "segclip_grad_sqnorm_ws_bytes": (C.c_size_t, [vp, i64]),
     "segclip_grad_sqnorm": (C.c_int, [vp, vp, i64, vp, vp, f32, vp]),

@@ -123,6 +123,46 @@ static inline int64_t colsum_chunks(int64_t M) {
   return c < 1 ? 1 : (c > CS_MAXCHUNK ? CS_MAXCHUNK : c);
 }
 
+// ---------------------------------------------------------------- positional-table interpolation (eval tier)
+// F.interpolate(mode='bicubic', align_corners=False) on a channel-last (n x n x D) table -> (h x w x D):
+// source coordinate (dst + 0.5) * in/out - 0.5 (not clamped), cubic-convolution weights with A = -0.75, tap indices
+// clamped to the border -- torch's upsample_bicubic2d.
+__device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+__global__ void interp_bicubic_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_in, int h, int w, int D) {
+  const int64_t total = (int64_t)h * w * D;
+  const float sy = (float)n_in / (float)h, sx = (float)n_in / (float)w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int ox = (int)((i / D) % w), oy = (int)(i / ((int64_t)D * w));
+    const float fy = sy * (oy + 0.5f) - 0.5f, fx = sx * (ox + 0.5f) - 0.5f;
+    const float iyf = floorf(fy), ixf = floorf(fx);
+    float wy[4], wx[4];
+    cubic_weights(fy - iyf, wy);
+    cubic_weights(fx - ixf, wx);
+    const int iy = (int)iyf, ix = (int)ixf;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(iy - 1 + a, 0), n_in - 1);
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max(ix - 1 + b, 0), n_in - 1);
+        row += wx[b] * src[((int64_t)yy * n_in + xx) * D + d];
+      }
+      acc += wy[a] * row;
+    }
+    dst[i] = acc;
+  }
+}
+
 // ---------------------------------------------------------------- vision front end
 // layout 0: col = c*p*p + py*p + px (conv1 weight order) ; layout 1: col = (py*p + px)*C + c (MAE patchify)
 __global__ void im2col_kernel(const float* __restrict__ img, void* __restrict__ cols, int64_t B, int C, int H, int W,
@@ -620,5 +660,12 @@ extern "C" int segclip_mask_sort(const float* noise, int64_t* ids_shuffle, int64
   hipLaunchKernelGGL(mask_sort_kernel, dim3((unsigned)B), dim3(256), (size_t)L * sizeof(float), ST, noise, ids_shuffle,
                      ids_restore, mask, (int)L, (int)len_keep);
   SEGCLIP_CHECK_LAUNCH("mask_sort");
+  return 0;
+}
+extern "C" int segclip_interp_bicubic(const float* src, float* dst, int64_t n_in, int64_t h, int64_t w, int64_t D,
+                                      void* stream) {
+  SEGCLIP_REQUIRE(n_in > 0 && h > 0 && w > 0 && D > 0, "interp_bicubic: empty grid");
+  hipLaunchKernelGGL(interp_bicubic_kernel, dim3(grid1d(h * w * D)), dim3(TPB), 0, ST, src, dst, (int)n_in, (int)h, (int)w, (int)D);
+  SEGCLIP_CHECK_LAUNCH("interp_bicubic");
   return 0;
 }

@@ -26,12 +26,18 @@ class VisualTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
     def get_pos_embed(self, h_, w_):
-        """modules/module_clip_vtransformer.py:35-53.  Training: the raw table.  Eval at a different grid
-        needs the bicubic interpolation of the segmentation-evaluation tier."""
+        """modules/module_clip_vtransformer.py:35-53.  Training: the raw table.  Eval at a different grid: the
+        patch rows are resampled bicubically (F.interpolate(..., mode='bicubic', align_corners=False)) by
+        segclip_interp_bicubic; the result is cached per (grid, table version)."""
         n = self.positional_embedding.shape[0] - 1
         if self.training or (h_ * w_ == n and h_ == w_):
             return self.positional_embedding
-        raise NotImplementedError("positional-embedding interpolation belongs to the zero-shot eval tier (8f-3)")
+        key = (h_, w_, self.positional_embedding._version, self.positional_embedding.data_ptr())
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = ops.interp_pos_table(self.positional_embedding, h_, w_)
+        return cache[key]
 
     def forward(self, x: torch.Tensor, video_frame=-1, mask_ratio=0.):
         B, _, H, W = x.shape

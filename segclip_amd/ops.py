@@ -263,6 +263,18 @@ def _wgrad_stream():
     return st
 
 
+def interp_pos_table(table, h, w):
+    """(1 + n*n, D) positional table -> (1 + h*w, D): class row kept, patch rows bicubically resampled
+    (modules/module_clip_vtransformer.py:35-53, eval only: no gradient)."""
+    n = int(round(math.sqrt(table.shape[0] - 1)))
+    D = table.shape[1]
+    src = table.detach().float().contiguous()
+    out = torch.empty(1 + h * w, D, dtype=torch.float32, device=table.device)
+    out[0] = src[0]
+    L.check(L.load().segclip_interp_bicubic(_off(src, D), _off(out, D), n, h, w, D, L.stream()), "interp_bicubic")
+    return out
+
+
 _WCAST_PARAMS = {}  # id -> weakref of every Parameter that went through wcast (the GEMM weights)
 
 

@@ -213,3 +213,68 @@ def test_ddp_wrapper_and_rccl_gather_single_rank():
             assert torch.allclose(g0[n], g1[n], rtol=0, atol=1e-6 * float(g0[n].abs().max()) + 1e-12), n
     finally:
         segclip_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_inference_subset_matches_reference_golden(dtype):
+    """SURVEY 8f-3 (zero-shot segmentation tier): eval-mode encode_image at 2x the training resolution (bicubic
+    positional-table resampling through segclip_interp_bicubic, 4x the tokens, no Gumbel noise) and encode_text,
+    against vectors produced by the REAL reference in eval mode (tests/golden/eval_tiny.npz)."""
+    g = load_golden("eval_tiny.npz")
+    spec = synth.SPECS["tiny"]
+    segclip_amd.set_compute_dtype(dtype)
+    try:
+        model, _ = synth.build_model(spec, {}, device=DEV)
+        model.eval()
+        with torch.no_grad():
+            for k in g.files:
+                if k.startswith("pos_"):
+                    h, w = (int(v) for v in k[4:].split("x"))
+                    got = model.clip.visual.get_pos_embed(h, w).cpu().numpy()
+                    np.testing.assert_allclose(got, g[k], rtol=1e-5, atol=2e-6, err_msg=k)
+            image = torch.from_numpy(g["image"]).to(DEV)
+            feat, hidden, mid = model.clip.encode_image(image, return_hidden=True)
+            tfeat, thidden = model.clip.encode_text(torch.from_numpy(g["input_ids"]).to(DEV), return_hidden=True)
+        tol = 1e-3 if dtype == torch.float32 else 6e-2
+        assert float((feat.cpu() - torch.from_numpy(g["image_feat"])).abs().max()) <= tol
+        assert float((hidden.cpu() - torch.from_numpy(g["image_hidden"])).abs().max()) <= tol
+        soft = mid["attns"][0]["soft_attn"].cpu()
+        assert float((soft - torch.from_numpy(g["soft_attn"])).abs().max()) <= (1e-3 if dtype == torch.float32 else 5e-2)
+        same = (mid["hard_idx"].cpu().long().numpy() == g["hard_idx"]).mean()
+        assert same == 1.0 if dtype == torch.float32 else same >= 0.9, same
+        assert float((tfeat.cpu() - torch.from_numpy(g["text_feat"])).abs().max()) <= tol
+        assert float((thidden.cpu() - torch.from_numpy(g["text_hidden"])).abs().max()) <= tol
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
+
+
+def test_eval_vitb16_448_sliding_window_size_vs_oracle():
+    """The evaluation tier's real shape: ViT-B/16 at 448^2 (28x28 = 784 patches + 8 centers, table resampled from 14x14),
+    one image, exact-f32 mode against the CPU oracle; bf16 mode against the f32 result."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["vitb16"]
+    gen = torch.Generator().manual_seed(77)
+    image = torch.randn(1, 3, 448, 448, generator=gen)
+    outs = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        segclip_amd.set_compute_dtype(dtype)
+        try:
+            model, _ = synth.build_model(spec, {}, device=DEV)
+            model.eval()
+            with torch.no_grad():
+                feat, hidden, mid = model.clip.encode_image(image.to(DEV), return_hidden=True)
+            outs[dtype] = (feat.cpu(), mid["attns"][0]["soft_attn"].cpu(), mid["hard_idx"].cpu().long())
+        finally:
+            segclip_amd.set_compute_dtype(torch.float32)
+    P = oracle_params(spec, model_param_shapes(spec, {}), requires_grad=False)
+    with torch.no_grad():
+        of, _, _, _, omid = so.encode_image(image, P, spec, gumbel=None, eval_pos_interp=True)
+    feat, soft, idx = outs[torch.float32]
+    assert soft.shape == (1, 8, 784)
+    assert float((feat - of).abs().max()) <= 1e-3
+    assert float((soft - omid["attns"][0]["soft_attn"]).abs().max()) <= 1e-3
+    assert torch.equal(idx, omid["hard_idx"])
+    bfeat, bsoft, bidx = outs[torch.bfloat16]
+    assert float((bfeat - of).abs().max()) <= 6e-2
+    assert float((bidx == idx).float().mean()) >= 0.97

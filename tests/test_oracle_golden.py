@@ -73,3 +73,25 @@ def test_zero_and_none_grad_contract():
     none = {n for n, p in P.items() if p.requires_grad and p.grad is None}
     assert all(("layers_mae2" in n or "reconstruct_layer2" in n) for n in none) and none
     assert float(P["clip.visual.class_embedding"].grad.abs().max()) == 0.0
+
+
+def test_eval_mode_inference_subset_matches_reference():
+    """eval-mode positional-table resampling (bicubic) and encode_image at 2x resolution / encode_text,
+    against tests/golden/eval_tiny.npz (the real reference in eval mode)."""
+    g = load_golden("eval_tiny.npz")
+    spec = synth.SPECS["tiny"]
+    P = oracle_params(spec, model_param_shapes(spec, {}), requires_grad=False)
+    pos = P["clip.visual.positional_embedding"]
+    for k in g.files:
+        if k.startswith("pos_"):
+            h, w = (int(v) for v in k[4:].split("x"))
+            np.testing.assert_allclose(so.interp_pos_embed(pos, h, w).numpy(), g[k], rtol=1e-5, atol=2e-6, err_msg=k)
+    feat, hidden, _, _, mid = so.encode_image(torch.from_numpy(g["image"]), P, spec, gumbel=None, eval_pos_interp=True)
+    np.testing.assert_allclose(mid["hidden"].numpy(), g["layers0_out"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(feat.numpy(), g["image_feat"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(hidden.numpy(), g["image_hidden"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(mid["attns"][0]["soft_attn"].numpy(), g["soft_attn"], rtol=2e-4, atol=2e-6)
+    assert np.array_equal(mid["hard_idx"].numpy(), g["hard_idx"])
+    tfeat, thidden, _ = so.encode_text(torch.from_numpy(g["input_ids"]), P, spec)
+    np.testing.assert_allclose(tfeat.numpy(), g["text_feat"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(thidden.numpy(), g["text_hidden"], rtol=2e-4, atol=2e-5)
