@@ -80,6 +80,22 @@ class AdaptAdamW(Optimizer):
         st = self.state[p]
         return 0 if len(st) == 0 else max(st['step'] - self._nan_skips(), 0)
 
+    def state_dict(self):
+        """torch.optim format with the reference's meaning of state['step'] (NaN-skipped iterations excluded), so
+        a `pytorch_opt.bin.N` written here resumes under either implementation (main_task_align.py:258-273)."""
+        sd = super().state_dict()
+        skips = self._nan_skips()
+        if skips:
+            sd = dict(sd, state={k: dict(v, step=max(v['step'] - skips, 0)) for k, v in sd['state'].items()})
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        skips = self._nan_skips()  # the device counter keeps running: re-bias the host-side count
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] = int(st['step']) + skips
+
     @torch.no_grad()
     def get_lr(self, with_grad_only=True):
         """Scheduled lr of every parameter that currently has a gradient (the reference's rule); with

@@ -128,6 +128,37 @@ def prep_optimizer(args, model, num_train_optimization_steps, device=None, n_gpu
     return optimizer, None, model, scaler
 
 
+def save_model(epoch, args, model, optimizer, tr_loss, scaler=None, type_name=""):
+    """main_task_align.py:258-273: bare model state_dict -> pytorch_model.bin.<epoch>, optimizer/epoch/loss ->
+    pytorch_opt.bin.<epoch> (same file names and dictionary keys, so either implementation can resume the other)."""
+    import os
+    tag = "{}{}".format("" if type_name == "" else type_name + ".", epoch)
+    model_file = os.path.join(args.output_dir, "pytorch_model.bin." + tag)
+    opt_file = os.path.join(args.output_dir, "pytorch_opt.bin." + tag)
+    torch.save(_unwrap(model).state_dict(), model_file)
+    torch.save({'epoch': epoch, 'optimizer_state_dict': optimizer.state_dict(), 'loss': tr_loss,
+                'scaler': scaler.state_dict() if scaler is not None else {}}, opt_file)
+    logger.info("Model saved to %s", model_file)
+    logger.info("Optimizer saved to %s", opt_file)
+    return model_file
+
+
+def load_model(epoch, args, n_gpu, device, model_file=None):
+    """main_task_align.py:275-290: state_dict file -> SegCLIP.from_pretrained(state_dict=...) -> device; None if absent."""
+    import os
+    from .modules.modeling import SegCLIP
+    if model_file is None or len(model_file) == 0:
+        model_file = os.path.join(args.output_dir, "pytorch_model.bin.{}".format(epoch))
+    if not os.path.exists(model_file):
+        return None
+    state = torch.load(model_file, map_location='cpu')
+    if getattr(args, "local_rank", 0) == 0:
+        logger.info("Model loaded from %s", model_file)
+    model = SegCLIP.from_pretrained(cache_dir=getattr(args, "cache_dir", None), state_dict=state, task_config=args)
+    model.to(device)
+    return model
+
+
 class TrainTail:
     """clip_grad_norm_ + optimizer.step + zero_grad + logit_scale clamp with no host synchronisation."""
 

@@ -131,6 +131,10 @@ def test_nan_loss_skips_on_device_and_shadow_tracks_param():
     assert st["nan_skips"] == 2 and st["steps"] == 5 and st["loss_sum"] == pytest.approx(3.25)
     assert math.isclose(ls.item(), min(ls.item(), math.log(100)))
     assert opt.state[w]["step"] == 5 and opt.effective_step(w) == 3 == ref_opt.state["w"]["step"]
+    sd = opt.state_dict()                                  # checkpoints carry the reference's meaning of 'step'
+    assert all(v["step"] == 3 for v in sd["state"].values()) and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    opt.load_state_dict(sd)
+    assert opt.state[w]["step"] == 5 and opt.effective_step(w) == 3
     # logit_scale clamp
     with torch.no_grad():
         ls.fill_(9.0)
@@ -208,3 +212,61 @@ def test_train_trajectory_bf16_tracks_reference():
             n_shadow += 1
             assert sh[1] == p._version and torch.equal(sh[0], p.detach().to(torch.bfloat16)), n
     assert n_shadow > 20
+
+
+def test_checkpoint_round_trip_resumes_identically(tmp_path):
+    """save_model / load_model (main_task_align.py:258-290 file names and dictionary keys): 2 iterations, checkpoint,
+    fresh model + optimizer from the files, third iteration == the uninterrupted third iteration."""
+    from segclip_amd.modules.module_clip import CLIP
+    g = load_golden("train_tiny_t18.npz")
+    spec = synth.SPECS["tiny"]
+    B = int(g["batch"])
+
+    def loader_and_noise(steps):
+        loader, inject = [], []
+        for s in steps:
+            b = synth.synthetic_batch(spec, B, seed=100 + s)
+            nz = synth.synthetic_noise(spec, B, seed=100 + s, device=DEV)
+            loader.append((b["input_ids"], b["input_mask"], b["segment_ids"], b["image"], torch.zeros(B, 4), b["image_seg"]))
+            inject += noise_items(nz, FULL_FLAGS)
+        return loader, inject
+
+    def fresh():
+        model, margs = synth.build_model(spec, FULL_FLAGS, device=DEV)
+        args = golden_args(g, n_display=1000, epochs=1, output_dir=str(tmp_path), cache_dir=None, **vars(margs))
+        train.freeze_parameters(args, model)
+        opt, sched, model, scaler = train.prep_optimizer(args, model, int(g["t_total"]), shadow_bf16=False)
+        return model, args, opt, scaler
+
+    def run(model, args, opt, scaler, steps, gstep):
+        loader, inject = loader_and_noise(steps)
+        with segclip_amd.noise_injection(inject):
+            return train.train_epoch(0, args, model, loader, torch.device(DEV), 1, opt, None, gstep, scaler)
+
+    try:
+        model, args, opt, scaler = fresh()
+        run(model, args, opt, scaler, [0, 1, 2], 0)
+        want = {n: p.detach().clone() for n, p in model.named_parameters()}
+
+        model, args, opt, scaler = fresh()
+        loss, gstep = run(model, args, opt, scaler, [0, 1], 0)
+        f = train.save_model(0, args, model, opt, loss, scaler)
+        assert f.endswith("pytorch_model.bin.0") and (tmp_path / "pytorch_opt.bin.0").exists()
+        orig = CLIP.get_config
+        CLIP.get_config = staticmethod(lambda pretrained_clip_name="ViT-B/16": synth.synthetic_clip_state_dict(spec))
+        try:
+            model2 = train.load_model(0, args, 1, torch.device(DEV))
+            assert train.load_model(7, args, 1, torch.device(DEV)) is None
+        finally:
+            CLIP.get_config = orig
+        model2.train()
+        train.freeze_parameters(args, model2)
+        opt2, _, model2, scaler2 = train.prep_optimizer(args, model2, int(g["t_total"]), shadow_bf16=False)
+        ck = torch.load(tmp_path / "pytorch_opt.bin.0", map_location=DEV)
+        assert set(ck) == {"epoch", "optimizer_state_dict", "loss", "scaler"}
+        opt2.load_state_dict(ck["optimizer_state_dict"])
+        run(model2, args, opt2, scaler2, [2], gstep)
+        for n, p in model2.named_parameters():
+            assert torch.allclose(p.detach(), want[n], rtol=1e-6, atol=1e-7), n
+    finally:
+        segclip_amd.config.trust_weight_shadows = False

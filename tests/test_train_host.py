@@ -13,7 +13,8 @@ from tests.helpers import FULL_FLAGS, load_golden
 
 def golden_args(g, **over):
     d = {k[5:]: float(g[k]) if g[k].dtype.kind == "f" else int(g[k]) for k in g.files if k.startswith("arg::")}
-    d.update(pretrained_clip_name="ViT-B/16", **over)
+    d.update(pretrained_clip_name="ViT-B/16")
+    d.update(over)
     return types.SimpleNamespace(**d)
 
 
