@@ -504,6 +504,9 @@ class ResBlockFn(Function):
         B, T, D, n_head, causal, act, act_dtype = ctx.cfg
         M = B * T
         hd = D // n_head
+        st = getattr(g, "_segclip_bf16", None)  # bf16 copy left by the next block's LayerNorm backward (same object)
+        if st is not None and (st.numel() != g.numel() or st.device != g.device or not g.is_contiguous()):
+            st = None
         g = g.contiguous().view(M, D)
         need = ctx.needs_input_grad
         bf = act_dtype == torch.bfloat16
@@ -512,8 +515,7 @@ class ResBlockFn(Function):
         # is handed to the next block through a side channel on the gradient tensor.
         g16 = g
         if bf:
-            st = getattr(g, "_segclip_bf16", None)
-            g16 = st if (st is not None and st.shape == g.shape and st.device == g.device) else p_cast(g, act_dtype)
+            g16 = st.view(M, D) if st is not None else p_cast(g, act_dtype)
         # The weight gradients do not feed the data-gradient chain: they are enqueued on a second HIP stream and
         # run concurrently with the dgrad / LayerNorm / attention kernels of the chain (their tiles fill the CUs
         # that the chain's partial last rounds and store phases leave idle).
