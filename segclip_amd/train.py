@@ -122,8 +122,11 @@ def prep_optimizer(args, model, num_train_optimization_steps, device=None, n_gpu
                            shadow_bf16=shadow_bf16)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         ids = [local_rank] if next(model.parameters()).is_cuda else None
+        # find_unused_parameters like main_task_align.py:251; static_graph spares DDP's per-iteration device->host sync
+        # of the used-parameter bitmap (the unused set is fixed for a given flag combination)
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, output_device=ids[0] if ids else None,
-                                                          find_unused_parameters=True)
+                                                          find_unused_parameters=True, static_graph=True,
+                                                          gradient_as_bucket_view=True, bucket_cap_mb=64)
     scaler = torch.amp.GradScaler("cuda", enabled=False)
     return optimizer, None, model, scaler
 
