@@ -160,6 +160,12 @@ class AdaptAdamW(Optimizer):
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 state['step'] += 1
                 shadow = None
+                if not (self.shadow_bf16 and p.dim() >= 2):
+                    # the kernel rewrites the parameter through its raw pointer (no autograd version bump): a bf16
+                    # copy that ops.wcast made earlier must not survive it
+                    stale = getattr(p, "_segclip_shadow", None)
+                    if stale is not None:
+                        stale[1] = -1
                 if self.shadow_bf16 and p.dim() >= 2:  # GEMM operands only
                     sh = getattr(p, "_segclip_shadow", None)
                     if sh is None:

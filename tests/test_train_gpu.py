@@ -270,3 +270,15 @@ def test_checkpoint_round_trip_resumes_identically(tmp_path):
             assert torch.allclose(p.detach(), want[n], rtol=1e-6, atol=1e-7), n
     finally:
         segclip_amd.config.trust_weight_shadows = False
+
+
+def test_fused_step_without_shadows_invalidates_cached_bf16_copies():
+    """The fused step writes parameters through raw pointers; a bf16 copy cached by ops.wcast must be re-made."""
+    from segclip_amd import ops
+    w = torch.nn.Parameter(torch.randn(48, 40, generator=torch.Generator().manual_seed(1)).to(DEV))
+    opt = AdaptAdamW([w], lr=1e-1, weight_decay=0.0, shadow_bf16=False)
+    before = ops.wcast(w, torch.bfloat16).clone()
+    w.grad = torch.ones_like(w)
+    opt.step()
+    after = ops.wcast(w, torch.bfloat16)
+    assert torch.equal(after, w.detach().to(torch.bfloat16)) and not torch.equal(after, before)

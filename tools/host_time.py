@@ -17,13 +17,14 @@ if ddp:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=("--no-unused" not in sys.argv),
-                                                    gradient_as_bucket_view=True, bucket_cap_mb=64,
+                                                    gradient_as_bucket_view=("--no-view" not in sys.argv),
+                                                    bucket_cap_mb=int(os.environ.get("BUCKET_MB", "64")),
                                                     static_graph=("--static" in sys.argv))
 b = synth.synthetic_batch(spec, 256, seed=0, device="cuda", with_seg=False)
 
 
 def step():
-    net.zero_grad(set_to_none=True)
+    net.zero_grad(set_to_none=("--keep-grads" not in sys.argv))
     loss = net(b["input_ids"], b["segment_ids"], b["input_mask"], b["image"])
     loss.backward()
 
