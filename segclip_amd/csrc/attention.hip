@@ -13,6 +13,8 @@
 //             recomputed in both passes (no atomics, deterministic).
 // f32 path (exact parity mode): S = scale*Q K^T, row softmax, O = P V as three launches of the f32 MFMA
 //   GEMM + a softmax kernel; P is kept for backward (5 GEMMs + one elementwise kernel).
+#include <stdlib.h>
+
 #include "common.h"
 
 int segclip_gemm_f32_launch(const segclip_gemm_desc* d, hipStream_t stream);
@@ -197,8 +199,20 @@ struct BwdArgs {
 };
 
 constexpr int TMAX = 256;
-// LDS bytes of the backward kernel for tiles of tp (padded) rows: Q,K,V,dO tiles + lse,D,cs,rs vectors + reduce pad
-static inline size_t bwd_lds_bytes(int tp) { return (size_t)tp * (4 * ROWB + 4 * 4) + 8 * 3 * 64 * 4; }
+// LDS bytes of the backward kernel for tiles of tp (padded) rows: two tiles (Q,dO for the dK/dV pass, then K,V for
+// the dQ pass in the same space) + lse, D, cs vectors + the cross-wave reduce pad
+static inline size_t bwd_lds_bytes(int tp) { return (size_t)tp * (2 * ROWB + 3 * 4) + 8 * 3 * 64 * 4; }
+
+// MFMA operand fragment straight from global memory (rows that only ONE wave needs): lane l -> row row0 + (l&31),
+// cols kc*16 + 8*(l>>5) .. +7; zero beyond nvalid / hd.  Unconditional load from a clamped address + select.
+__device__ __forceinline__ bf16x8_t frag_rows_g(const bf16_t* __restrict__ X, int64_t st, int row0, int nvalid, int kc,
+                                                int lane, int hd) {
+  const int r = row0 + (lane & 31), c = kc * 16 + 8 * (lane >> 5);
+  const int rc = r < nvalid ? r : nvalid - 1, cc = c < hd ? c : 0;
+  u32x4 v = *reinterpret_cast<const u32x4*>(X + (int64_t)rc * st + cc);
+  if (!(r < nvalid && c < hd)) v = u32x4{0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
 
 __device__ __forceinline__ void store_acc_T(bf16_t* base, int64_t st, int row, int nrows, int hd, const f32x16 (&acc)[2],
                                             int lh) {
@@ -219,19 +233,22 @@ __device__ __forceinline__ void store_acc_T(bf16_t* base, int64_t st, int row, i
 }
 
 __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
-  // dynamic LDS sized by the padded sequence length: a 77-token text head needs 57 KB (two workgroups per CU)
-  // instead of the 133 KB of a 256-row allocation
+  // Dynamic LDS sized by the padded sequence length, and only TWO tiles: Q and dO (read by every wave in the dK/dV
+  // pass), later overwritten by K and V (read by every wave in the dQ pass).  The rows only one wave needs (its own
+  // key tile of K,V / query tile of Q,dO) come straight from global memory.  197 tokens -> 66 KB, 77 -> 31 KB, so
+  // two (vision) or more (text) workgroups share a CU and one's load/store phases overlap the other's MFMAs.
   extern __shared__ __attribute__((aligned(16))) char smem_bwd[];
   const int tp0 = (((a.Tq > a.Tk ? a.Tq : a.Tk) + 31) & ~31);
-  char* Qt = smem_bwd;
-  char* Kt = smem_bwd + tp0 * ROWB;
-  char* Vt = smem_bwd + 2 * tp0 * ROWB;
-  char* Gt = smem_bwd + 3 * tp0 * ROWB;  // dO
-  float* Ls = reinterpret_cast<float*>(smem_bwd + 4 * tp0 * ROWB);
+  char* T0 = smem_bwd;               // Q, then K
+  char* T1 = smem_bwd + tp0 * ROWB;  // dO, then V
+  char* Qt = T0;
+  char* Gt = T1;
+  char* Kt = T0;
+  char* Vt = T1;
+  float* Ls = reinterpret_cast<float*>(smem_bwd + 2 * tp0 * ROWB);
   float* Ds = Ls + tp0;
   float* Cs = Ds + tp0;   // cs[key] = sum_q dS[q][key]
-  float* Rs = Cs + tp0;   // rs[q]   = sum_key dS[q][key]
-  float* Red = Rs + tp0;  // [8 waves][3][64]
+  float* Red = Cs + tp0;  // [8 waves][3][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int li = lane & 31, lh = lane >> 5;
@@ -244,8 +261,6 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
   const int tqp = (a.Tq + 31) & ~31, tkp = (a.Tk + 31) & ~31;
 
   stage_rows(Qt, Qp, a.q_st, 0, a.Tq, tqp, a.hd, tid, blockDim.x);
-  stage_rows(Kt, Kp, a.k_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
-  stage_rows(Vt, Vp, a.v_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
   // dO tile + D[q] = sum_d dO*O (8 consecutive lanes share a row); branch-free batched loads as in stage_rows
   {
     const int total = tqp * 8;
@@ -290,7 +305,10 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
   for (int k0 = wave * 32; k0 < tkp; k0 += nw * 32) {
     bf16x8_t kf[4], vf[4];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) { kf[kc] = frag_rows(Kt, k0, kc, lane); vf[kc] = frag_rows(Vt, k0, kc, lane); }
+    for (int kc = 0; kc < 4; ++kc) {
+      kf[kc] = frag_rows_g(Kp, a.k_st, k0, a.Tk, kc, lane, a.hd);
+      vf[kc] = frag_rows_g(Vp, a.v_st, k0, a.Tk, kc, lane, a.hd);
+    }
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
@@ -337,15 +355,37 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
     if (lh == 0) Cs[key] = csl;
   }
 
+  // token sums of dV (= token sums of dO: the rows of P sum to one) while dO is still in LDS
+  float accv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) accv[j] = 0.f;
+  if (a.colsum_part) {
+    const int c = tid & 7, nrl = (int)blockDim.x >> 3;
+    for (int r = tid >> 3; r < tqp; r += nrl) {
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(Gt + swz(r, c * 8));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        accv[2 * j] += __uint_as_float(gv[j] << 16);
+        accv[2 * j + 1] += __uint_as_float(gv[j] & 0xffff0000u);
+      }
+    }
+  }
+  __syncthreads();  // every wave is done with Q and dO: the two tiles become K and V
+  stage_rows(Kt, Kp, a.k_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
+  stage_rows(Vt, Vp, a.v_st, 0, a.Tk, tkp, a.hd, tid, blockDim.x);
+  __syncthreads();
+
   // ---------------- pass B: this wave owns query tiles; dQ ----------------
   for (int q0 = wave * 32; q0 < tqp; q0 += nw * 32) {
     bf16x8_t qf[4], gf[4];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) { qf[kc] = frag_rows(Qt, q0, kc, lane); gf[kc] = frag_rows(Gt, q0, kc, lane); }
+    for (int kc = 0; kc < 4; ++kc) {
+      qf[kc] = frag_rows_g(Qp, a.q_st, q0, a.Tq, kc, lane, a.hd);
+      gf[kc] = frag_rows_g(Gp, a.do_st, q0, a.Tq, kc, lane, a.hd);
+    }
     const int q = q0 + li;
     const float lq = Ls[q], dq_ = Ds[q];
     f32x16 dq[2];
-    float rsl = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
     for (int k0 = 0; k0 < tkp; k0 += 32) {
@@ -365,7 +405,6 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
         const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
         const float pv = ok ? __expf(s[r] * a.scale - lq) : 0.f;
         ds[r] = pv * (dp[r] - dq_) * a.scale;
-        rsl += ds[r];
       }
       const bf16x8_t sb0 = pack8(ds), sb1 = pack8(ds + 8);
 #pragma unroll
@@ -375,61 +414,44 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
       }
     }
     store_acc_T(a.dQ + b * a.dq_sb + hoff, a.dq_st, q, a.Tq, a.hd, dq, lh);
-    rsl += __shfl_xor(rsl, 32, 64);
-    if (lh == 0) Rs[q] = rsl;
   }
 
-  // ---------------- token sums of dQ, dK, dV from the tiles still in LDS (in_proj bias gradient) ----------------
-  //   sum_q dQ[q][d] = sum_key K[key][d] cs[key];  sum_key dK[key][d] = sum_q Q[q][d] rs[q]  (zero up to rounding:
-  //   softmax is shift invariant);  sum_key dV[key][d] = sum_q dO[q][d]  (the rows of P sum to one).
+  // ---------------- token sums of dQ, dK, dV (in_proj bias gradient of this sample and head) ----------------
+  //   sum_q dQ[q][d]   = sum_key K[key][d] cs[key]   (K is in LDS now, cs from the dK/dV pass)
+  //   sum_key dV[key][d] = sum_q dO[q][d]            (accumulated above)
+  //   sum_key dK[key][d] = sum_q Q[q][d] rowsum_key(dS[q][:]) = 0 exactly: the rows of dS sum to zero (softmax is
+  //                        shift invariant; what the reference accumulates there is rounding noise ~1e-8)
   if (a.colsum_part) {
-    __syncthreads();
     const int c = tid & 7, nrl = (int)blockDim.x >> 3;
-    float acc[3][8];
+    float accq[8];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int j = 0; j < 8; ++j) accq[j] = 0.f;
+    for (int r = tid >> 3; r < tkp; r += nrl) {
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(Kt + swz(r, c * 8));
+      const float w = Cs[r];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
-    const int tmax = tqp > tkp ? tqp : tkp;
-    for (int r = tid >> 3; r < tmax; r += nrl) {
-      const int off = swz(r, c * 8);
-      if (r < tkp) {
-        const u32x4 kv = *reinterpret_cast<const u32x4*>(Kt + off);
-        const float w = Cs[r];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0][2 * j] += w * __uint_as_float(kv[j] << 16);
-          acc[0][2 * j + 1] += w * __uint_as_float(kv[j] & 0xffff0000u);
-        }
-      }
-      if (r < tqp) {
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(Qt + off);
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(Gt + off);
-        const float w = Rs[r];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[1][2 * j] += w * __uint_as_float(qv[j] << 16);
-          acc[1][2 * j + 1] += w * __uint_as_float(qv[j] & 0xffff0000u);
-          acc[2][2 * j] += __uint_as_float(gv[j] << 16);
-          acc[2][2 * j + 1] += __uint_as_float(gv[j] & 0xffff0000u);
-        }
+      for (int j = 0; j < 4; ++j) {
+        accq[2 * j] += w * __uint_as_float(kv[j] << 16);
+        accq[2 * j + 1] += w * __uint_as_float(kv[j] & 0xffff0000u);
       }
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = acc[m][j];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 8) Red[(wave * 3 + m) * 64 + c * 8 + j] = v;
+    for (int j = 0; j < 8; ++j) {
+      float vq = accq[j], vv = accv[j];
+      vq += __shfl_xor(vq, 8, 64); vv += __shfl_xor(vv, 8, 64);
+      vq += __shfl_xor(vq, 16, 64); vv += __shfl_xor(vv, 16, 64);
+      vq += __shfl_xor(vq, 32, 64); vv += __shfl_xor(vv, 32, 64);
+      if (lane < 8) {
+        Red[(wave * 3 + 0) * 64 + c * 8 + j] = vq;
+        Red[(wave * 3 + 2) * 64 + c * 8 + j] = vv;
       }
+    }
     __syncthreads();
     for (int t = tid; t < 192; t += (int)blockDim.x) {
       const int m = t >> 6, dd = t & 63;
       float v = 0.f;
-      for (int w = 0; w < nw; ++w) v += Red[(w * 3 + m) * 64 + dd];
+      if (m != 1)
+        for (int w = 0; w < nw; ++w) v += Red[(w * 3 + m) * 64 + dd];
       if (dd < a.hd) a.colsum_part[((int64_t)b * 3 + m) * ((int64_t)a.H * a.hd) + hoff + dd] = v;
     }
   }
@@ -554,7 +576,12 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.dq_sb = d->dq_sb; a.dq_st = d->dq_st; a.dk_sb = d->dk_sb; a.dk_st = d->dk_st; a.dv_sb = d->dv_sb; a.dv_st = d->dv_st;
     a.scale = d->scale; a.causal = d->causal;
     const int tiles = (int)cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32);
-    const int nw = tiles < 8 ? tiles : 8;
+    // 4 waves per workgroup (each wave walks over 1-2 tiles): two such workgroups fit the registers (2 waves per SIMD
+    // at ~215 VGPRs) and the LDS of a CU, so their load / MFMA / store phases interleave.  SEGCLIP_ATTN_BWD_WAVES
+    // overrides (benchmarking).
+    static const int force_waves = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_WAVES"); return e ? atoi(e) : 0; }();
+    int nw = tiles < 4 ? tiles : 4;
+    if (force_waves >= 1 && force_waves <= 8) nw = tiles < force_waves ? tiles : force_waves;
     a.colsum_part = (float*)d->colsum_part;
     const int tp = (int)(cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32) * 32);
     const size_t lds = bwd_lds_bytes(tp);
