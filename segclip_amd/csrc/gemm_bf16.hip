@@ -282,11 +282,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
 // C = alpha * sum_s slab[s]  (split-K combine; deterministic order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, int64_t M, int64_t N, int64_t ldc,
                                      int64_t nb2, int64_t bsC1, int64_t bsC2, int splits, int64_t nz, float alpha,
-                                     int c_dtype, int64_t stride) {
+                                     int c_dtype) {
   const int64_t total = nz * M * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * stride + i];
+    for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * total + i];
     v *= alpha;
     const int64_t z = i / (M * N), rem = i % (M * N), m = rem / N, n = rem % N;
     const int64_t o = (z / nb2) * bsC1 + (z % nb2) * bsC2 + m * ldc + n;
@@ -294,40 +294,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, in
   }
 }
 
-// contiguous fp32/bf16 C (ldc == N, one batch).  Workgroup = 64 float4 columns x 4 slab groups: lane (c, sg) sums
-// slabs sg, sg+4, ... with every load in flight at once (the sum over up to 32 slabs is one memory latency deep),
-// then the four groups meet in LDS in a fixed order (deterministic).
+// contiguous fp32/bf16 C (ldc == N, one batch): 16-byte loads, four slabs in flight, no index arithmetic
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ slab, void* __restrict__ C,
-                                                                int64_t total4, int splits, float alpha, int c_dtype,
-                                                                int64_t stride4) {
-  __shared__ f32x4 red[3][64];
-  const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + cl;
+                                                                int64_t total4, int splits, float alpha, int c_dtype) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(slab) + i;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (i < total4) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + i;
+  int s = 0;
+#pragma unroll 1
+  for (; s + 8 <= splits; s += 8) {
     f32x4 t[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int s = sg + 4 * u;
-      t[u] = p[(int64_t)(s < splits ? s : splits - 1) * stride4];  // branch-free: clamped address, masked below
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (sg + 4 * u >= splits) t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    v = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    for (int s = sg + 32; s < splits; s += 4) v += p[(int64_t)s * stride4];
+    for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(s + u) * total4];
+    v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   }
-  if (sg > 0) red[sg - 1][cl] = v;
-  __syncthreads();
-  if (sg == 0 && i < total4) {
-    v = (v + red[0][cl]) + (red[1][cl] + red[2][cl]);
-    v *= alpha;
-    if (c_dtype == SEGCLIP_BF16)
-      reinterpret_cast<u32x2*>(C)[i] = u32x2{pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
-    else
-      reinterpret_cast<f32x4*>(C)[i] = v;
+  if (s + 4 <= splits) {
+    const f32x4 a = p[(int64_t)s * total4], b = p[(int64_t)(s + 1) * total4], c = p[(int64_t)(s + 2) * total4],
+                d = p[(int64_t)(s + 3) * total4];
+    v += (a + b) + (c + d);
+    s += 4;
   }
+  for (; s < splits; ++s) v += p[(int64_t)s * total4];
+  v *= alpha;
+  if (c_dtype == SEGCLIP_BF16)
+    reinterpret_cast<u32x2*>(C)[i] = u32x2{pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+  else
+    reinterpret_cast<f32x4*>(C)[i] = v;
 }
 
 }  // namespace
@@ -446,11 +439,11 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     const int64_t cal = d->c_dtype == SEGCLIP_BF16 ? 7 : 15;
     if (nb == 1 && d->ldc == d->N && total % 4 == 0 && (reinterpret_cast<uintptr_t>(d->C) & cal) == 0 &&
         (reinterpret_cast<uintptr_t>(d->ws) & 15) == 0)
-      hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)cdiv(total / 4, 64)), dim3(256), 0, stream,
-                         (const float*)d->ws, d->C, total / 4, g.splits, d->alpha, d->c_dtype, total / 4);
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)cdiv(total / 4, 256)), dim3(256), 0, stream,
+                         (const float*)d->ws, d->C, total / 4, g.splits, d->alpha, d->c_dtype);
     else
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->ws, d->C, d->M,
-                       d->N, d->ldc, g.nb2, d->bsC1, d->bsC2, g.splits, nb, d->alpha, d->c_dtype, total);
+                       d->N, d->ldc, g.nb2, d->bsC1, d->bsC2, g.splits, nb, d->alpha, d->c_dtype);
     SEGCLIP_CHECK_LAUNCH("splitk_reduce");
   }
   return 0;

@@ -9,30 +9,27 @@
 
 namespace {
 
-// RL = row lanes per workgroup (64 or 256): with 256 a 1024-row partial matrix needs four loads per lane, all in
-// flight at once (one memory latency instead of a chain of batches).
-template <int RL>
-__global__ __launch_bounds__(RL * 4) void reduce_rows_kernel(const float* __restrict__ part, int64_t rows, int64_t width,
-                                                             int64_t ld, float* __restrict__ out0,
-                                                             float* __restrict__ out1, float* __restrict__ out2,
-                                                             int64_t seg) {
-  constexpr int NW = RL * 4 / 64;
-  __shared__ f32x4 red[NW][4];
-  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;  // a wave holds 16 row lanes x 4 column lanes
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int64_t rows, int64_t width,
+                                                          int64_t ld, float* __restrict__ out0, float* __restrict__ out1,
+                                                          float* __restrict__ out2, int64_t seg) {
+  __shared__ f32x4 red[4][4];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;  // rl 0..63; a wave holds 16 row lanes x 4 column lanes
   const int64_t c = ((int64_t)blockIdx.x * 4 + cl) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (c < width) {
     const float* p = part + c;
     int64_t r = rl;
+    // eight independent 16-byte loads in flight per lane (the chain is latency-, not bandwidth-bound)
 #pragma unroll 1
-    for (; r + 3 * RL < rows; r += 4 * RL) {
-      f32x4 v[4];
+    for (; r + 7 * 64 < rows; r += 8 * 64) {
+      f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (r + u * RL) * ld);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (r + u * 64) * ld);
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    for (; r < rows; r += RL) s += *reinterpret_cast<const f32x4*>(p + r * ld);
+    for (; r < rows; r += 64) s += *reinterpret_cast<const f32x4*>(p + r * ld);
   }
+  // 16 row lanes of a wave: lanes differ in bits 2..5
 #pragma unroll
   for (int o = 4; o < 64; o <<= 1) {
     s.x += __shfl_xor(s.x, o, 64);
@@ -44,9 +41,7 @@ __global__ __launch_bounds__(RL * 4) void reduce_rows_kernel(const float* __rest
   if ((threadIdx.x & 63) < 4) red[w][cl] = s;
   __syncthreads();
   if (threadIdx.x < 4 && c < width) {
-    f32x4 t = red[0][cl];
-#pragma unroll
-    for (int k = 1; k < NW; ++k) t += red[k][cl];
+    const f32x4 t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
     const float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -62,12 +57,8 @@ __global__ __launch_bounds__(RL * 4) void reduce_rows_kernel(const float* __rest
 // requires width % 4 == 0, ld % 4 == 0 and a 16-byte aligned `part`
 inline void launch_reduce_rows(const float* part, int64_t rows, int64_t width, int64_t ld, float* out0, float* out1,
                                float* out2, int64_t seg, hipStream_t st) {
-  if (rows >= 512)
-    hipLaunchKernelGGL(reduce_rows_kernel<256>, dim3((unsigned)cdiv(width, 16)), dim3(1024), 0, st, part, rows, width, ld,
-                       out0, out1, out2, seg);
-  else
-    hipLaunchKernelGGL(reduce_rows_kernel<64>, dim3((unsigned)cdiv(width, 16)), dim3(256), 0, st, part, rows, width, ld,
-                       out0, out1, out2, seg);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv(width, 16)), dim3(256), 0, st, part, rows, width, ld, out0,
+                     out1, out2, seg);
 }
 
 }  // namespace
