@@ -17,6 +17,8 @@
 // barrier per K-step).  All loads are unconditional from clamped addresses (no divergent branch around a
 // load).  Workgroup ids are remapped so each XCD walks a contiguous run of tiles (A panel reuse in its L2).
 // Split-K (grid.y) for the wgrad shapes, combined by a deterministic slab reduction.
+#include <stdlib.h>
+
 #include "gemm_bf16_common.h"
 #include "reduce_rows.h"
 
@@ -348,6 +350,16 @@ static int choose_splits(const segclip_gemm_desc* d) {
   if (d->bias || d->residual || d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact) return 1;
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
   const int64_t ksteps = cdiv(d->K, BK);
+  static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (want_dma(d) && force_tile == 128) {
+    // 128x128 tiles, two workgroups per CU: one round = 512 workgroups
+    const int64_t tiles = cdiv(d->M, 128) * cdiv(d->N, 128) * nb;
+    if (tiles >= 320 || ksteps < 32) return 1;
+    int64_t s = 512 / tiles;
+    if (s > ksteps / 8) s = ksteps / 8;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+  }
   if (want_dma(d)) {
     // 256-row tiles, long K loops: aim at one full round of the 256 CUs
     const int64_t bn = d->N > 128 ? 256 : 128;
