@@ -193,9 +193,10 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
               u32x4 p;
 #pragma unroll
               for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-              *reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n) = p;
+              __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n));
             } else {
-              *reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
+              __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
+                                          reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n));
             }
           }
 #pragma unroll

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (m < g.M) slab[m * g.N + n] = acc[i][j][r];
+          if (m < g.M) __builtin_nontemporal_store(acc[i][j][r], &slab[m * g.N + n]);
         }
       }
     return;
