@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int BK = 64, STAGES = 2;
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -99,7 +99,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // <BM, BN, NWV>: <256,256,8> and <256,128,8> own a CU (139 KiB of LDS: operand ring / epilogue patches);
 // <128,128,4> (waves 2x2, 64x64 each) needs 68 KiB, so two workgroups share a CU and one's output phase overlaps
 // the other's MFMA phase.
-template <bool A_KS, bool B_KS, int BM, int BN, int NWV>
+template <bool A_KS, bool B_KS, int BM, int BN, int NWV, int STAGES = 2>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kernel(Args g) {
   constexpr int SZA = BM * BK * 2;
   constexpr int SZB = BN * BK * 2;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kern
   const int nk = (int)((kend - kbeg) / BK);
 
   auto issue = [&](int t) {
-    char* la = smem + (t & 1) * SZS;
+    char* la = smem + (t % STAGES) * SZS;
     char* lb = la + SZA;
     const int64_t k0 = kbeg + (int64_t)t * BK;
     if constexpr (A_KS) issue_ks<BM, NWV>(A, g.lda, m0, g.M, k0, la, wave, lane);
@@ -158,12 +158,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kern
     while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   issue(0);
+  if constexpr (STAGES == 3) {
+    if (nk > 1) issue(1);
+  }
+  constexpr int DMA_PER_STAGE = (BM + BN) / (8 * NWV);  // DMA instructions per wave and k-tile
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t has landed
-    __builtin_amdgcn_s_barrier();                       // ... and everybody else's; buffer (t+1)&1 is free
+    // this wave's share of tile t has landed (with three stages the DMA of tile t+1 may still be in flight)
+    if (STAGES == 3 && t + 1 < nk) wait_vm<DMA_PER_STAGE>();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // ... and everybody else's; buffer (t-1)%STAGES is free
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nk) issue(t + 1);
-    const char* la = smem + (t & 1) * SZS;
+    if (t + STAGES - 1 < nk) issue(t + STAGES - 1);
+    const char* la = smem + (t % STAGES) * SZS;
     const char* lb = la + SZA;
     // fragments of k16-chunk kc+1 are requested before the MFMAs of chunk kc (register double buffer)
     bf16x8_t fa[2][TM], fb[2][2];
@@ -279,7 +285,8 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   // default and SEGCLIP_GEMM_TILE=128 selects this variant for experiments.
   static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const bool small = force_tile == 128;
-  const int bn = small ? 128 : pick_bn(d, nb * splits);
+  const bool three = force_tile == 3;  // experiment: 256x128 tiles with a 3-stage ring (96 KiB in flight)
+  const int bn = (small || three) ? 128 : pick_bn(d, nb * splits);
   const int bm = small ? 128 : 256;
   g.nbx = (int)cdiv(d->N, bn);
   g.nby = (int)cdiv(d->M, bm);
@@ -299,6 +306,7 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   do {                                                                                                            \
     if (small) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128, 128, 4>), grid, dim3(256), 0, stream, g);   \
     else if (bn == 256) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 256, 8>), grid, dim3(512), 0, stream, g); \
+    else if (three) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8, 3>), grid, dim3(512), 0, stream, g); \
     else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8>), grid, dim3(512), 0, stream, g);         \
   } while (0)
   if (!a_ks && !b_ks) GO(false, false);
