@@ -33,14 +33,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling: global = batch * N)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fixed global batch (SURVEY 8d: 2048), per-GPU batch = global / N")
     ap.add_argument("--spec", default="vitb16")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--full-loss", action="store_true", help="configs[3]: + superpixel-KL + MAE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the N>1 code path (RCCL group, DDP, barriers) even with one rank: single-GPU check of it")
+                    help="take the N>1 code path (RCCL group, GradSync, barriers) even with one rank: single-GPU check of it")
+    ap.add_argument("--grad-sync", default="segclip", choices=["segclip", "ddp"],
+                    help="N>1 gradient exchange: segclip_amd.dist.GradSync (default) or torch DDP (comparison only)")
+    ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format")
     return ap.parse_args()
 
 
@@ -78,13 +83,38 @@ def cpu_baseline():
             "loss": round(float(loss), 6)}
 
 
+def respawn(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over RCCL)
+    through torch.distributed.run and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but only {n_dev} GPU(s) visible")
+        respawn(a)
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.global_batch:
+        if a.global_batch % world:
+            raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} ranks")
+        a.batch = a.global_batch // world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or a.force_dist
@@ -102,13 +132,14 @@ def main():
     model.clip.visual.conv1.weight.requires_grad_(False)
     model.clip.visual.positional_embedding.requires_grad_(False)
     net = model
-    if multi:
+    if multi and a.grad_sync == "segclip":
+        # gradient all-reduce of the data-parallel step (the reference: DDP, main_task_align.py:251-252): flat aligned
+        # buckets filled directly by the weight-gradient kernels, exchanged on a communication stream as they complete
+        from segclip_amd.dist import GradSync
+        net = GradSync(model, compress={"auto": "auto", "bf16": True, "fp32": False}[a.wire])
+    elif multi:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
-                                                        find_unused_parameters=True, gradient_as_bucket_view=True,
-                                                        bucket_cap_mb=64, static_graph=True)
-        # static_graph: the set of unused parameters (class embedding, the MAE-only blocks) is fixed, so DDP learns it in
-        # the first iteration instead of all-reducing + copying a used-parameter bitmap to the HOST every iteration;
-        # that per-step device->host sync stopped the host from running ahead (measured 65.7 -> 62.0 ms/step, 1 rank)
+                                                        find_unused_parameters=True, bucket_cap_mb=64, static_graph=True)
     batch = synth.synthetic_batch(spec, a.batch, seed=100 + rank, device=dev, with_seg=a.full_loss)
 
     def step():
@@ -169,12 +200,17 @@ def main():
     if rank == 0:
         out = {"metric": "image-text pairs/s fwd+bwd, ViT-B/16 224^2, per-GPU batch 256 (global 2048 at 8 GPUs)",
                "value": round(pairs, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
+               "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": ("BASELINE configs[3]: ViT-B/16 224^2 + 77-token text, full SegCLIP loss"
                                        if a.full_loss else
                                        "BASELINE configs[1]/[2]: ViT-B/16 224^2 + 77-token text, contrastive loss only"),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "grad_exchange": (None if not multi else "torch DDP fp32" if a.grad_sync == "ddp" else
+                                            f"GradSync {len(net._flat)} buckets, wire " +
+                                            ("bf16" if net._flat and net._use_bf16(net._flat[0]) else "fp32") +
+                                            f", zero-copy grads {net.stats['zero_copy']}/{net.stats['zero_copy'] + net.stats['copies']}"),
                           "cross_mode": segclip_amd.config.cross_mode, "loss": round(loss_val, 5)},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))

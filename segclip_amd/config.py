@@ -1,60 +1,108 @@
-"""Run-time switches of the hot path (process-global, read at forward time).
+"""Run-time switches of the hot path.
+
+Every switch has a PROCESS DEFAULT (set_compute_dtype(), set_cross_mode(), or plain assignment
+`config.overlap_towers = False`) and may be overridden for the CURRENT THREAD by `config.scope(...)`;
+a model carries its own overrides in `model.segclip_config` (a dict), which SegCLIP.forward applies
+through scope() - so two models, or two threads, in one process can run in different modes.
 
 compute_dtype : torch.float32  -> exact-f32 MFMA kernels (parity gate: 1e-3 on loss/logits)
                 torch.bfloat16 -> bf16 MFMA kernels (throughput mode; fp32 residual stream/params)
 cross_mode    : "t18"      torch-1.8 key-buffer reinterpretation of CrossAttentionBlock (what the
                            published recipe trained with; SURVEY.md finding 0.4)
                 "intended" each sample attends to its own tokens
+overlap_wgrad : weight-gradient GEMMs of a block on a second HIP stream; measured SLOWER (64.4 vs 59.5 ms/step:
+                two 139-KiB-LDS GEMMs cannot share a CU and the interleaving delays the dgrad chain), kept off
+overlap_towers: enqueue the text tower on a second HIP stream (concurrent with the vision tower)
+trust_weight_shadows : False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
+                True: only weights whose autograd version changed (set per model by train.prep_optimizer when the
+                fused optimizer maintains the bf16 copies itself)
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
-                a list of ("gumbel"|"rand", tensor) consumed in call order -> parity runs.
+                noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
+                (thread-local).
 """
 import contextlib
+import sys
+import threading
+import types
 
 import torch
 
-compute_dtype = torch.float32
-cross_mode = "t18"
-overlap_wgrad = False  # weight-gradient GEMMs of a block on a second HIP stream; measured SLOWER (64.4 vs 59.5 ms/step:
-                       # two 139-KiB-LDS GEMMs cannot share a CU and the interleaving delays the dgrad chain), kept off
-overlap_towers = True  # enqueue the text tower on a second HIP stream (concurrent with the vision tower)
-trust_weight_shadows = False  # False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
-                              # True: only weights whose autograd version changed (set by train.prep_optimizer when the
-                              # fused optimizer maintains the bf16 copies itself)
-_noise = None
+_DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
+                 trust_weight_shadows=False)
+_tls = threading.local()
+
+
+def _get(name):
+    ov = getattr(_tls, "overrides", None)
+    if ov:
+        for d in reversed(ov):
+            if name in d:
+                return d[name]
+    return _DEFAULTS[name]
+
+
+def _check(name, value):
+    if name == "compute_dtype" and value not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    if name == "cross_mode" and value not in ("t18", "intended"):
+        raise ValueError("cross_mode must be 't18' or 'intended'")
+    return value
+
+
+class _ConfigModule(types.ModuleType):
+    """Module type whose switches are properties: reads resolve thread-local overrides first, writes set the
+    process default."""
+
+
+for _n in _DEFAULTS:
+    setattr(_ConfigModule, _n, property(lambda self, _n=_n: _get(_n),
+                                        lambda self, v, _n=_n: _DEFAULTS.__setitem__(_n, _check(_n, v))))
+sys.modules[__name__].__class__ = _ConfigModule
 
 
 def set_compute_dtype(dtype):
-    global compute_dtype
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
-    compute_dtype = dtype
+    _DEFAULTS["compute_dtype"] = _check("compute_dtype", dtype)
 
 
 def set_cross_mode(mode):
-    global cross_mode
-    if mode not in ("t18", "intended"):
-        raise ValueError("cross_mode must be 't18' or 'intended'")
-    cross_mode = mode
+    _DEFAULTS["cross_mode"] = _check("cross_mode", mode)
+
+
+@contextlib.contextmanager
+def scope(**overrides):
+    """Thread-local overrides of the switches above for the duration of the block."""
+    for k, v in overrides.items():
+        if k not in _DEFAULTS:
+            raise KeyError(f"unknown switch {k!r}")
+        _check(k, v)
+    stack = getattr(_tls, "overrides", None)
+    if stack is None:
+        stack = _tls.overrides = []
+    stack.append(dict(overrides))
+    try:
+        yield
+    finally:
+        stack.pop()
 
 
 @contextlib.contextmanager
 def noise_injection(items):
     """items: list of (kind, tensor) in the order the forward consumes them."""
-    global _noise
-    prev = _noise
-    _noise = list(items)
+    prev = getattr(_tls, "noise", None)
+    _tls.noise = list(items)
     try:
         yield
     finally:
-        _noise = prev
+        _tls.noise = prev
 
 
 def _take(kind, shape, device):
-    if _noise is None:
+    noise = getattr(_tls, "noise", None)
+    if noise is None:
         return None
-    if not _noise:
+    if not noise:
         raise RuntimeError("noise_injection: more noise draws than injected tensors")
-    k, t = _noise.pop(0)
+    k, t = noise.pop(0)
     if k != kind or tuple(t.shape) != tuple(shape):
         raise RuntimeError(f"noise_injection: expected {kind}{tuple(shape)}, got {k}{tuple(t.shape)}")
     return t.to(device=device, dtype=torch.float32)

@@ -1,0 +1,251 @@
+"""Data-parallel gradient exchange of the hot path: the counterpart of the reference's
+`torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)` wrapper
+(main_task_align.py:251-252), built for how THIS backward produces gradients.
+
+Why not DistributedDataParallel: every residual block here is ONE autograd node (ops.ResBlockFn) whose
+parameter gradients become ready together, so DDP's per-parameter reducer hooks, bucket copies and
+unused-parameter bookkeeping are pure host/device overhead (+4.9 ms per step on one rank, round-1
+measurement), and its gradient_as_bucket_view packs a 1-element tensor (clip.logit_scale) in front of
+others, leaving their gradients 4-byte aligned - the fused optimizer needs 16.
+
+GradSync keeps one flat fp32 buffer per bucket; every trainable parameter owns a 256-byte aligned slot in
+it and `p.grad` IS a view of that slot.  The weight-gradient GEMMs write straight into the slots
+(ops.grad_slot_out), so a gradient is never copied.  A bucket whose slots are all written is exchanged
+at once: [cast fp32->bf16] -> RCCL all-reduce(AVG) -> [cast back], on a communication stream, overlapping
+the rest of the backward; the end-of-backward callback makes the compute stream wait for the last one.
+Buckets are laid out in the order gradients became ready in the first backward (rank 0's order,
+broadcast), and are always launched in index order, so every rank issues the same collective sequence.
+
+Semantics = DDP's: gradients are averaged over ranks after every backward (also under gradient
+accumulation, where the bucket holds previous-average + new-local, as with DDP); parameters that
+receive no gradient keep `grad is None` (find_unused_parameters=True behaviour).
+Wire format: bf16 when the model runs in bf16 mode (halves the xGMI bytes:
+ViT-B/16 627 MB -> 313 MB per step), fp32 otherwise or with compress=False.
+"""
+import weakref
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+_ALIGN = 64  # slot alignment in fp32 elements (256 bytes)
+
+
+class _Slot:
+    """A parameter's place in a flat gradient bucket."""
+    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner")
+
+    def __init__(self, bucket, offset, p, owner):
+        self.bucket, self.offset, self.numel, self.shape = bucket, offset, p.numel(), tuple(p.shape)
+        self.param = weakref.ref(p)
+        self.owner = weakref.ref(owner)
+
+    def view(self):
+        o = self.owner()
+        return o._flat[self.bucket][self.offset:self.offset + self.numel].view(self.shape)
+
+    def out_buffer(self):
+        """Fresh view to be used as the OUTPUT of a gradient kernel, or None when the parameter already
+        holds a gradient (accumulation: autograd must add, not alias) or the owner is not ready."""
+        o, p = self.owner(), self.param()
+        if o is None or p is None or not o._steady or p.grad is not None:
+            return None
+        return self.view()
+
+
+class GradSync(nn.Module):
+    def __init__(self, module, process_group=None, bucket_mb=64, compress="auto"):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.bucket_elems = max(int(bucket_mb * (1 << 20) // 4), 1)
+        self.compress = compress
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        self._index = {id(p): i for i, p in enumerate(self._params)}
+        self._steady = False
+        self._sync_enabled = True
+        self._first_order = []       # parameter indices in first-backward ready order
+        self._seen = set()
+        self._callback_queued = False
+        self._flat, self._wire, self._slots, self._bucket_params = [], [], {}, []
+        self._pending, self._next_bucket, self._launched, self._late, self._ready = [], 0, [], [], []
+        self._comm = None
+        self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0}
+        for p in self._params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        """Context manager: accumulate local gradients without exchanging them (DDP API)."""
+        outer = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.prev, outer._sync_enabled = outer._sync_enabled, False
+
+            def __exit__(self, *exc):
+                outer._sync_enabled = self.prev
+        return _Ctx()
+
+    # ------------------------------------------------------------------ backward-time hooks
+    def _queue_callback(self):
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _on_grad(self, p):
+        i = self._index[id(p)]
+        self._queue_callback()
+        if not self._steady:
+            if i not in self._seen:
+                self._seen.add(i)
+                self._first_order.append(i)
+            return
+        slot = self._slots.get(i)
+        if slot is None:   # became used after the layout was frozen: exchanged on its own at the end
+            self._late.append(p)
+            return
+        g = p.grad
+        v = slot.view()
+        if g.data_ptr() != v.data_ptr():
+            v.copy_(g)
+            p.grad = v
+            self.stats["copies"] += 1
+        else:
+            self.stats["zero_copy"] += 1
+        b = slot.bucket
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self._sync_enabled:
+            self._ready[b] = True
+            self._launch_ready()
+
+    def _launch_ready(self):
+        while self._next_bucket < len(self._flat) and self._ready[self._next_bucket]:
+            self._exchange(self._next_bucket)
+            self._next_bucket += 1
+
+    # ------------------------------------------------------------------ the collective
+    def _use_bf16(self, flat):
+        if self.compress is False or self.compress is None:
+            return False
+        if not flat.is_cuda:
+            return False     # the cast kernel is a HIP kernel; CPU/gloo runs exchange fp32
+        if self.compress == "auto":
+            from . import config
+            return config.compute_dtype == torch.bfloat16
+        return bool(self.compress)
+
+    def _exchange(self, b):
+        flat = self._flat[b]
+        self.stats["buckets"] += 1
+        if self.world == 1 and not dist.is_initialized():
+            return
+        nccl = dist.get_backend(self.group) == "nccl"
+        if flat.is_cuda and nccl:
+            from . import ops
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            main = torch.cuda.current_stream(flat.device)
+            self._comm.wait_stream(main)          # the bucket's producers are enqueued on `main` by now
+            with torch.cuda.stream(self._comm):
+                if self._use_bf16(flat):
+                    wire = self._wire[b]
+                    ops.p_cast_into(flat, wire)
+                    dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=self.group)
+                    ops.p_cast_into(wire, flat)
+                else:
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            self._launched.append(b)
+        else:   # gloo (CPU tensors, or the single-GPU multi-process tests): no AVG op, no bf16 wire format
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+
+    # ------------------------------------------------------------------ end of a backward pass
+    def _finalize(self):
+        self._callback_queued = False
+        if not self._steady:
+            self._build_layout()
+            return
+        if self._sync_enabled:
+            # buckets some of whose parameters got no gradient this pass (cannot happen with a static graph;
+            # kept so that a data-dependent branch degrades to a late exchange instead of a hang)
+            for b in range(self._next_bucket, len(self._flat)):
+                if any(self._params[i].grad is not None for i in self._bucket_params[b]):
+                    for i in self._bucket_params[b]:
+                        p = self._params[i]
+                        if p.grad is None:
+                            self._slots[i].view().zero_()
+                            p.grad = self._slots[i].view()
+                self._exchange(b)
+            for p in self._late:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+                p.grad.div_(self.world)
+        if self._comm is not None and self._launched:
+            torch.cuda.current_stream(self._flat[0].device).wait_stream(self._comm)
+        self._reset_pass()
+
+    def _reset_pass(self):
+        self._pending = [len(ps) for ps in self._bucket_params]
+        self._ready = [False] * len(self._flat)
+        self._next_bucket, self._launched, self._late = 0, [], []
+
+    def _build_layout(self):
+        """After the first backward: fix the bucket layout (rank 0's ready order), move the gradients into
+        their slots and exchange everything once."""
+        order = list(self._first_order)
+        if dist.is_initialized() and self.world > 1:
+            box = [order]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                                       group=self.group)
+            order = box[0]
+            mine = set(self._first_order)
+            if set(order) != mine:
+                raise RuntimeError("GradSync: ranks disagree on the set of parameters that receive gradients")
+        buckets, cur, cur_elems = [], [], 0
+        for i in order:
+            n = -(-self._params[i].numel() // _ALIGN) * _ALIGN
+            if cur and cur_elems + n > self.bucket_elems:
+                buckets.append((cur, cur_elems))
+                cur, cur_elems = [], 0
+            cur.append((i, cur_elems))
+            cur_elems += n
+        if cur:
+            buckets.append((cur, cur_elems))
+        self._flat, self._wire, self._slots, self._bucket_params = [], [], {}, []
+        for b, (items, elems) in enumerate(buckets):
+            dev = self._params[items[0][0]].device
+            flat = torch.zeros(elems, dtype=torch.float32, device=dev)
+            self._flat.append(flat)
+            self._wire.append(torch.empty(elems, dtype=torch.bfloat16, device=dev) if flat.is_cuda else None)
+            self._bucket_params.append([i for i, _ in items])
+            for i, off in items:
+                p = self._params[i]
+                slot = _Slot(b, off, p, self)
+                self._slots[i] = slot
+                p._segclip_gslot = slot
+                v = slot.view()
+                v.copy_(p.grad)
+                p.grad = v
+        self._steady = True
+        self._reset_pass()
+        if self._sync_enabled:
+            for b in range(len(self._flat)):
+                self._exchange(b)
+            if self._comm is not None and self._launched:
+                torch.cuda.current_stream(self._flat[0].device).wait_stream(self._comm)
+        self._reset_pass()
+
+    # ------------------------------------------------------------------ introspection (tests, bench)
+    def layout(self):
+        return [(b, [self._params[i].shape for i in ps], int(self._flat[b].numel())) for b, ps in
+                enumerate(self._bucket_params)]
+
+
+def grad_slot_out(param):
+    """Output buffer for `param`'s gradient inside its GradSync slot, or None (no GradSync / accumulating)."""
+    slot = getattr(param, "_segclip_gslot", None)
+    return slot.out_buffer() if slot is not None else None

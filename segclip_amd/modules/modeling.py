@@ -107,6 +107,12 @@ class SegCLIP(SegCLIPPreTrainedModel):
             raise NotImplementedError("text-MAE reconstruction is outside the hot path (SURVEY.md section 2.1)")
         self.use_seglabel = get_attr(task_config, "use_seglabel", default_value=False)
         self.apply(self.init_weights)
+        # per-model overrides of the run-time switches (segclip_amd/config.py), e.g. {"compute_dtype": torch.bfloat16}
+        self.segclip_config = {}
+
+    def scope(self):
+        """Context manager applying this model's switch overrides (forward() does this itself)."""
+        return config.scope(**self.segclip_config)
 
     def _text_stream(self):
         st = getattr(self, "_side_stream", None)
@@ -119,6 +125,12 @@ class SegCLIP(SegCLIPPreTrainedModel):
     def forward(self, input_ids, token_type_ids, attention_mask, image, image_seg=None):
         """modules/modeling.py:174-256.  token_type_ids / attention_mask are accepted and ignored on this
         path exactly like the reference."""
+        if self.segclip_config:
+            with config.scope(**self.segclip_config):
+                return self._forward(input_ids, token_type_ids, attention_mask, image, image_seg)
+        return self._forward(input_ids, token_type_ids, attention_mask, image, image_seg)
+
+    def _forward(self, input_ids, token_type_ids, attention_mask, image, image_seg=None):
         input_ids = input_ids.view(-1, input_ids.shape[-1])
         L.require_cuda(input_ids, torch.as_tensor(image))  # fail loudly: there is no CPU / eager fallback
         image_input = torch.as_tensor(image).float()

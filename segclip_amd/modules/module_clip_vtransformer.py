@@ -25,6 +25,12 @@ class VisualTransformer(nn.Module):
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
+    def train(self, mode=True):
+        # the fused optimizer rewrites parameters through raw pointers (no autograd version bump), so a resampled
+        # table cached before a training phase may be stale: drop it at every train()/eval() switch
+        self.__dict__.pop("_pos_cache", None)
+        return super().train(mode)
+
     def get_pos_embed(self, h_, w_):
         """modules/module_clip_vtransformer.py:35-53.  Training: the raw table.  Eval at a different grid: the
         patch rows are resampled bicubically (F.interpolate(..., mode='bicubic', align_corners=False)) by

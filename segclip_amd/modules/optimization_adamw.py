@@ -134,6 +134,14 @@ class AdaptAdamW(Optimizer):
             with torch.enable_grad():
                 ret = closure()
         lib = L.load()
+        if ctrl is not None and self._ctrl is not None and ctrl is not self._ctrl and ctrl.data_ptr() != self._ctrl.data_ptr():
+            # a new control block (e.g. a fresh TrainTail per epoch) starts its NaN-skip counter at zero: fold the old
+            # counter into the host-side step counts so that `step - nan_skips` keeps the reference's meaning
+            old = self._nan_skips() - int(ctrl.view(torch.int32)[2].item())
+            if old:
+                for st in self.state.values():
+                    if 'step' in st:
+                        st['step'] = max(int(st['step']) - old, 0)
         tensors, keep = [], []
         groups = (L.AdamWGroup * len(self.param_groups))()
         for gi, group in enumerate(self.param_groups):

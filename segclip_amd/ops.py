@@ -150,21 +150,36 @@ def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=Fa
     return dx
 
 
-def p_wgrad(dy, x, w_kn=False):
-    """dw = dy^T x (N,K) fp32  [or x^T dy (K,N) when w_kn];  dy (M,N), x (M,K)."""
+def _slot_of(w):
+    """GradSync slot of a Parameter (segclip_amd/dist.py), looked up at forward time."""
+    return getattr(w, "_segclip_gslot", None)
+
+
+def _slot_out(slot, shape):
+    """Gradient output buffer inside the parameter's all-reduce bucket (zero-copy), or None."""
+    if slot is None:
+        return None
+    out = slot.out_buffer()
+    if out is not None and tuple(out.shape) != tuple(shape):
+        out = out.view(shape) if out.numel() == math.prod(shape) else None
+    return out
+
+
+def p_wgrad(dy, x, w_kn=False, out=None):
+    """dw = dy^T x (N,K) fp32  [or x^T dy (K,N) when w_kn];  dy (M,N), x (M,K).  `out`: preallocated fp32 result."""
     M, N = dy.shape
     K = x.shape[1]
     if w_kn:
         if x.dtype == torch.float32 and dy.dtype != torch.float32:
             x = p_cast(x, dy.dtype)
-        dw = _empty((K, N), torch.float32, dy)
+        dw = out if out is not None else _empty((K, N), torch.float32, dy)
         if dy.dtype == torch.float32 and x.dtype != torch.float32:
             dy = p_cast(dy, x.dtype)
         p_gemm(x, dy, dw, K, N, M, (1, _ld(x)), (1, _ld(dy)), N)
         return dw
     if x.dtype == torch.float32 and dy.dtype != torch.float32:
         x = p_cast(x, dy.dtype)  # only the A operand may be fp32 on the bf16 path
-    dw = _empty((N, K), torch.float32, dy)
+    dw = out if out is not None else _empty((N, K), torch.float32, dy)
     p_gemm(dy, x, dw, N, K, M, (1, _ld(dy)), (1, _ld(x)), K)
     return dw
 
@@ -369,6 +384,7 @@ class LinearFn(Function):
         ctx.save_for_backward(x, wc, aux)
         ctx.act, ctx.w_kn, ctx.has_b, ctx.has_r = act, w_kn, b is not None, residual is not None
         ctx.act_dtype = act_dtype
+        ctx.gslot = _slot_of(w)
         return y
 
     @staticmethod
@@ -381,7 +397,10 @@ class LinearFn(Function):
             L.check(L.load().segclip_act_bwd(L.ptr(dy), L.ptr(aux), L.ptr(du), dy.numel(), ctx.act, L.dt(dy),
                                              L.stream()), "act_bwd")
         dx = p_dgrad(du, wc, x.dtype, w_kn=ctx.w_kn) if ctx.needs_input_grad[0] else None
-        dw = p_wgrad(du, x, w_kn=ctx.w_kn) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            shp = (x.shape[1], du.shape[1]) if ctx.w_kn else (du.shape[1], x.shape[1])
+            dw = p_wgrad(du, x, w_kn=ctx.w_kn, out=_slot_out(ctx.gslot, shp))
         db = p_colsum(du) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None
@@ -495,6 +514,7 @@ class ResBlockFn(Function):
         ctx.save_for_backward(x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2,
                               wfc_c, u, h, wpr_c)
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
+        ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
         return xo.view(B, T, D)
 
     @staticmethod
@@ -522,6 +542,8 @@ class ResBlockFn(Function):
         from . import config as _cfg
         main = torch.cuda.current_stream()
         side = _wgrad_stream() if _cfg.overlap_wgrad else None
+        sq, so, sf, sp = ctx.gslots  # weight gradients land directly in their all-reduce bucket (segclip_amd/dist.py)
+        F4 = wfc_c.shape[0]
 
         def on_side(fn, *deps):
             if side is None:
@@ -535,16 +557,16 @@ class ResBlockFn(Function):
 
         # ---- MLP
         du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True)  # (dy c_proj)*act'(u), colsum
-        dwpr = on_side(lambda: p_wgrad(g16, h)) if need[11] else None
+        dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)))) if need[11] else None
         dy2 = p_dgrad(du, wfc_c, act_dtype)
-        dwfc = on_side(lambda: p_wgrad(du, y2)) if need[9] else None
+        dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)))) if need[9] else None
         r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
         dx1, dln2w, dln2b = r[0], r[1], r[2]
         dx1_16 = r[3] if bf else dx1
         dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
         # ---- attention
         do = p_dgrad(dx1_16, wo_c, act_dtype)
-        dwo = on_side(lambda: p_wgrad(dx1_16, o)) if need[5] else None
+        dwo = on_side(lambda: p_wgrad(dx1_16, o, out=_slot_out(so, (D, D)))) if need[5] else None
         dqkv = _empty((M, 3 * D), act_dtype, g)
         s3 = (T * 3 * D, 3 * D)
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
@@ -552,7 +574,7 @@ class ResBlockFn(Function):
         part = _empty((B, 3 * D), torch.float32, g) if (bf and need[4]) else None  # in_proj bias gradient per sample
         p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
         dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
-        dwqkv = on_side(lambda: p_wgrad(dqkv, y1)) if need[3] else None
+        dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)))) if need[3] else None
         dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv)) if need[4] else None
         r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
         dx, dln1w, dln1b = r[0], r[1], r[2]
@@ -656,6 +678,7 @@ class EmbedFn(Function):
                 "embed_fwd")
         ctx.save_for_backward(ids)
         ctx.shape = (B, Lq, D, V, tuple(pos.shape))
+        ctx.gslot = _slot_of(table)
         return out
 
     @staticmethod
@@ -663,7 +686,10 @@ class EmbedFn(Function):
         (ids,) = ctx.saved_tensors
         B, Lq, D, V, pshape = ctx.shape
         dout = dout.contiguous()
-        dtable = torch.zeros((V, D), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1] else None
+        dtable = None
+        if ctx.needs_input_grad[1]:
+            dtable = _slot_out(ctx.gslot, (V, D))
+            dtable = dtable.zero_() if dtable is not None else torch.zeros((V, D), dtype=torch.float32, device=dout.device)
         dpos_l = _empty((Lq, D), torch.float32, dout) if ctx.needs_input_grad[2] else None
         L.check(L.load().segclip_embed_bwd(L.ptr(ids), L.ptr(dout), L.ptr(dtable), L.ptr(dpos_l), B, Lq, D, V,
                                            L.stream()), "embed_bwd")
@@ -793,7 +819,10 @@ class SuperpixelKLFn(Function):
     def forward(ctx, hard, seg):
         B, G, T = hard.shape
         hard = hard.contiguous()
-        seg = seg.contiguous().view(B, T)
+        L.require_cuda(hard, seg)
+        if seg.is_floating_point() or seg.dtype == torch.bool:
+            raise TypeError(f"superpixel_kl: image_seg must hold integer superpixel labels, got {seg.dtype}")
+        seg = seg.to(torch.int64).contiguous().view(B, T)   # the kernel reads int64; loaders may hand over int32 / uint8
         lib = L.load()
         lr = _empty((B,), torch.float32, hard)
         dh = torch.empty_like(hard)
@@ -884,6 +913,14 @@ class AllGatherFn(Function):
         if ctx.world == 0:   # no process group: single-process run, identity
             return x
         x = x.contiguous()
+        if x.is_cuda and dist.get_backend() != "nccl":
+            # gloo has no device all-gather (only broadcast / all-reduce take GPU tensors): the single-GPU
+            # multi-process tests gather by summing rank-disjoint slices, which is exact
+            out = torch.zeros((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            r = dist.get_rank()
+            out[r * x.shape[0]:(r + 1) * x.shape[0]] = x
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            return out
         out = torch.empty((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x)
         return out

@@ -95,7 +95,7 @@ def param_group_index(name):
 def prep_optimizer(args, model, num_train_optimization_steps, device=None, n_gpu=1, local_rank=0, coef_lr=1.,
                    shadow_bf16=None):
     """Same return tuple as the reference: (optimizer, scheduler, model, scaler).  The model is wrapped in
-    DistributedDataParallel(find_unused_parameters=True) when a process group with more than one rank exists;
+    segclip_amd.dist.GradSync (DDP's contract) when a process group with more than one rank exists;
     AMP is permanently disabled in the reference (main_task_align.py:78), so the scaler is a disabled GradScaler."""
     model = _unwrap(model)
     buckets = [[] for _ in range(8)]
@@ -113,20 +113,22 @@ def prep_optimizer(args, model, num_train_optimization_steps, device=None, n_gpu
     from . import config
     if shadow_bf16 is None:
         shadow_bf16 = config.compute_dtype == torch.bfloat16
-    if shadow_bf16:
-        config.trust_weight_shadows = True  # the optimizer kernel rewrites the bf16 copies together with the weights
+    if shadow_bf16 and hasattr(model, "segclip_config"):
+        # the optimizer kernel rewrites the bf16 copies together with the weights: THIS model's forward may trust them
+        # (scoped to the model, not the process - ADVICE r1)
+        model.segclip_config["trust_weight_shadows"] = True
     optimizer = AdaptAdamW(groups, lr=args.lr, warmup=args.warmup_proportion, schedule='warmup_cosine',
                            b1=args.opt_b1, b2=args.opt_b2, e=args.eps, t_total=num_train_optimization_steps,
                            weight_decay=args.weight_decay, max_grad_norm=1.0,
                            lr_start=getattr(args, "lr_start", 0.), lr_end=getattr(args, "lr_end", 0.),
                            shadow_bf16=shadow_bf16)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        ids = [local_rank] if next(model.parameters()).is_cuda else None
-        # find_unused_parameters like main_task_align.py:251; static_graph spares DDP's per-iteration device->host sync
-        # of the used-parameter bitmap (the unused set is fixed for a given flag combination)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, output_device=ids[0] if ids else None,
-                                                          find_unused_parameters=True, static_graph=True,
-                                                          gradient_as_bucket_view=True, bucket_cap_mb=64)
+        # The reference wraps the model in DistributedDataParallel(find_unused_parameters=True)
+        # (main_task_align.py:251-252).  GradSync (segclip_amd/dist.py) has the same contract - `.module`, gradients
+        # averaged over ranks after every backward, unused parameters keep grad None - without DDP's per-parameter
+        # reducer: flat, 256-byte aligned gradient buckets the weight-gradient kernels write into directly.
+        from .dist import GradSync
+        model = GradSync(model)
     scaler = torch.amp.GradScaler("cuda", enabled=False)
     return optimizer, None, model, scaler
 
@@ -216,7 +218,13 @@ def train_epoch(epoch, args, model, train_dataloader, device, n_gpu, optimizer, 
     model.train()
     log_step = getattr(args, "n_display", 100)
     acc = max(int(getattr(args, "gradient_accumulation_steps", 1)), 1)
-    tail = tail or TrainTail(model, optimizer, getattr(args, "clip_grad", 1.0))
+    if tail is None:
+        # one TrainTail (device control block with the NaN-skip counter) per optimizer, kept across epochs: the
+        # optimizer's host-side step counts are relative to that counter (AdaptAdamW.effective_step)
+        tail = getattr(optimizer, "_segclip_tail", None)
+        if tail is None or tail.model is not model:
+            tail = TrainTail(model, optimizer, getattr(args, "clip_grad", 1.0))
+            optimizer._segclip_tail = tail
     start_sum = tail.read()["loss_sum"]
     partial = None  # losses of the micro-steps that do not end in an optimizer step
     start_time = time.time()

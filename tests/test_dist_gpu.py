@@ -1,0 +1,164 @@
+"""GPU: the data-parallel (N>1) path of the PRODUCT - SegCLIP.forward with rank/world_size, the differentiable
+embedding all-gather (modules/util_module.py:180-190, modules/modeling.py:204-206) and the gradient exchange
+(main_task_align.py:251-252 uses DDP; here segclip_amd.dist.GradSync).
+
+The GPU box has ONE MI355X, and RCCL refuses two ranks on one device, so:
+  * two REAL ranks (two processes sharing the GPU) run over gloo - same product code, same collective semantics -
+    and are held to the per-rank vectors the REAL reference produced under a 2-rank gloo group
+    (tests/golden/tiny_w2_t18.npz);
+  * the RCCL ("nccl") calls themselves are exercised with a 1-rank group (all-gather / reduce-scatter / all-reduce
+    through GradSync, bf16 wire format, zero-copy gradient slots, fused optimizer on the bucket views)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import FULL_FLAGS, load_golden, noise_items  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_worker(rank, world, port, out, seed, B):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import segclip_amd
+    from segclip_amd import synth
+    from segclip_amd.dist import GradSync
+    spec = synth.SPECS["tiny"]
+    segclip_amd.set_compute_dtype(torch.float32)
+    segclip_amd.set_cross_mode("t18")
+    model, _ = synth.build_model(spec, FULL_FLAGS, rank=rank, world_size=world, device="cuda")
+    gb = synth.synthetic_batch(spec, B * world, seed=seed, device="cuda")
+    gn = synth.synthetic_noise(spec, B * world, seed=seed, device="cuda")
+    sl = slice(rank * B, (rank + 1) * B)
+    batch = {k: v[sl] for k, v in gb.items()}
+    noise = {k: v[sl] for k, v in gn.items()}
+
+    def run(net):
+        net.zero_grad(set_to_none=True)
+        with segclip_amd.noise_injection(noise_items(noise, FULL_FLAGS)):
+            loss = net(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"],
+                       image_seg=batch["image_seg"])
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss
+
+    # (1) plain model: per-rank LOCAL gradients (what the reference golden holds: it ran without DDP)
+    loss = run(model)
+    local = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    res = dict(loss=float(loss), lc=float(model.last_losses["contrastive"]), t2v=model.last_logits[0].cpu(),
+               v2t=model.last_logits[1].cpu(), hard_idx=model.last_mid_states["hard_idx"].cpu().long(),
+               ids_restore=model.last_mae[1].cpu(),
+               gn={n: float(g.double().norm()) for n, g in local.items()})
+    # (2) through GradSync: first pass builds the bucket layout, second runs the bucketed steady state
+    net = GradSync(model)
+    for it in range(2):
+        run(net)
+        worst = 0.0
+        for n, p in model.named_parameters():
+            if n not in local:
+                assert p.grad is None, n
+                continue
+            e = local[n].clone()
+            dist.all_reduce(e)
+            e /= world
+            err = float((p.grad - e).abs().max())
+            worst = max(worst, err / (float(e.abs().max()) + 1e-12))
+            assert err <= 1e-5 * float(e.abs().max()) + 1e-9, (it, n, err)
+            assert p.grad.data_ptr() % 256 == 0
+    res["zero_copy"], res["copies"], res["nbuckets"] = net.stats["zero_copy"], net.stats["copies"], len(net._flat)
+    torch.save(res, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_product_two_ranks_on_one_gpu_matches_reference_per_rank():
+    g = load_golden("tiny_w2_t18.npz")
+    world, B, seed = int(g["world"]), int(g["B"]), int(g["seed"])
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(), "res")
+    mp.spawn(_two_rank_worker, args=(world, _free_port(), out, seed, B), nprocs=world, join=True)
+    names = g["grad_names"].tolist()
+    for r in range(world):
+        res = torch.load(f"{out}.{r}")
+        assert abs(res["loss"] - float(g[f"r{r}_loss"])) <= 1e-4, (r, res["loss"], float(g[f"r{r}_loss"]))
+        assert abs(res["lc"] - float(g[f"r{r}_loss_contrastive"])) <= 1e-4
+        np.testing.assert_allclose(res["t2v"].numpy(), g[f"r{r}_t2v"], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(res["v2t"].numpy(), g[f"r{r}_v2t"], rtol=0, atol=1e-3)
+        assert np.array_equal(res["hard_idx"].numpy(), g[f"r{r}_hard_idx"])
+        assert np.array_equal(res["ids_restore"].numpy(), g[f"r{r}_ids_restore"])
+        for n, ref in zip(names, g[f"r{r}_grad_norms"]):
+            assert abs(res["gn"][n] - ref) <= 5e-3 * max(ref, 1e-4), (r, n, res["gn"][n], ref)
+        assert res["nbuckets"] >= 1 and res["zero_copy"] > 0, res   # weight-gradient GEMMs wrote into their slots
+
+
+def test_rccl_single_rank_gradsync_bf16_wire_and_fused_optimizer():
+    """nccl (= RCCL) group of one rank: all-gather / reduce-scatter of the embeddings, bucketed all-reduce with the bf16
+    wire format, and the fused optimizer reading the bucket views (DDP's bucket views were 4-byte aligned and
+    the optimizer kernel rejects them).  A 1-rank average is the identity up to the bf16 round trip."""
+    import argparse
+    import segclip_amd
+    from segclip_amd import synth, train
+    from segclip_amd.dist import GradSync
+    spec = synth.SPECS["tiny"]
+    segclip_amd.set_compute_dtype(torch.bfloat16)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        model, _ = synth.build_model(spec, {}, device="cuda")
+        batch = synth.synthetic_batch(spec, 4, seed=13, device="cuda", with_seg=False)
+        noise = synth.synthetic_noise(spec, 4, seed=13, device="cuda")
+
+        def run(net):
+            net.zero_grad(set_to_none=True)
+            with segclip_amd.noise_injection([("gumbel", noise["gumbel_main"])]):
+                loss = net(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"])
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss
+
+        l0 = run(model)
+        g0 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        for wire, tol in ((True, 2.0 ** -8), (False, 0.0)):
+            net = GradSync(model, compress=wire)
+            for _ in range(3):
+                l1 = run(net)
+            assert abs(float(l0) - float(l1)) <= 1e-6
+            assert net.stats["zero_copy"] > 0 and len(net._flat) >= 1
+            for n, p in model.named_parameters():
+                if n not in g0:
+                    assert p.grad is None, n
+                    continue
+                assert p.grad.data_ptr() % 256 == 0
+                err = float((p.grad - g0[n]).abs().max())
+                assert err <= tol * float(g0[n].abs().max()) + 1e-12, (wire, n, err)
+        # the fused clip + AdaptAdamW tail on the bucket views
+        args = argparse.Namespace(lr=1e-3, lower_lr=0., lower_text_lr=0., weight_decay=0.2, warmup_proportion=0.1,
+                                  opt_b1=0.9, opt_b2=0.98, eps=1e-6, pretrained_clip_name="ViT-B/16")
+        optimizer, _, _, _ = train.prep_optimizer(args, model, 10)
+        tail = train.TrainTail(net, optimizer)
+        before = model.clip.visual.proj.detach().clone()
+        for _ in range(2):
+            loss = run(net)
+            tail.run(loss)
+        st = tail.read()
+        assert st["steps"] == 2 and st["nan_skips"] == 0 and np.isfinite(st["grad_norm"])
+        assert float((model.clip.visual.proj.detach() - before).abs().max()) > 0
+    finally:
+        dist.destroy_process_group()
+        segclip_amd.set_compute_dtype(torch.float32)
+        pass

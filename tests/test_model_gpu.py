@@ -110,8 +110,9 @@ def test_bf16_mode_error_is_bounded(spec_name, B):
     print(f"\n[bf16 {spec_name}] loss {float(loss):.5f} vs ref {float(g['loss']):.5f}; "
           f"max |dlogit| {float((model.last_logits[0].cpu() - torch.from_numpy(g['t2v'])).abs().max()):.4f}; "
           f"hard_idx agreement {float((model.last_mid_states['hard_idx'].cpu().numpy() == g['hard_idx']).mean()):.4f}")
-    assert abs(float(loss) - float(g["loss"])) <= 0.08
-    assert float((model.last_logits[0].cpu() - torch.from_numpy(g["t2v"])).abs().max()) <= 0.5
+    # ~3x the errors measured on MI355X (vitb16 B=4, round 1: |d loss| 0.002, max |d logit| 0.023); printed above
+    assert abs(float(loss) - float(g["loss"])) <= 0.015
+    assert float((model.last_logits[0].cpu() - torch.from_numpy(g["t2v"])).abs().max()) <= 0.1
     assert torch.isfinite(torch.stack([p.grad.float().norm() for p in model.parameters() if p.grad is not None])).all()
 
 
