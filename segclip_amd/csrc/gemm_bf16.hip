@@ -329,6 +329,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
 
 bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t kper, int64_t nb,
                                hipStream_t stream);
+bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t kper, int64_t nb,
+                              hipStream_t stream);
+int segclip_gemm_bf16_dma_pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits);
 
 static bool aligned16(const segclip_gemm_desc* d) {
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -423,7 +426,14 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     }
     g.colsum_part = d->colsum_ws;
   }
-  if (want_dma(d)) launched = segclip_gemm_bf16_dma_try(d, &g, g.splits, g.kper, nb, stream);
+  if (want_dma(d)) {
+    static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    // 256x256 tiles: the phase-pipelined kernel (gemm_bf16_p8.hip); 256x128 / 128x128 tiles: the one-barrier-per-K-tile
+    // kernel (gemm_bf16_dma.hip)
+    if (force_tile == 0 && segclip_gemm_bf16_dma_pick_bn(d, nb * g.splits) == 256)
+      launched = segclip_gemm_bf16_p8_try(d, &g, g.splits, g.kper, nb, stream);
+    if (!launched) launched = segclip_gemm_bf16_dma_try(d, &g, g.splits, g.kper, nb, stream);
+  }
   if (d->colsum && (!launched || !g.colsum_part)) {
     segclip_set_error("gemm: fused colsum unsupported for this shape");
     return SEGCLIP_ERR_UNSUPPORTED;

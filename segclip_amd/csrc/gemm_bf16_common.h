@@ -27,16 +27,18 @@ template <> __device__ __forceinline__ float ldc_<float>(const void* p, int64_t 
 
 // FULL: whole 128x128 tile in range (no per-element bounds checks; bf16 output stored as packed column
 // pairs after a lane^1 exchange: 4-byte stores instead of 2-byte ones).
+// jstride: distance between the two 32-column MFMA tiles of the sub-tile (32: adjacent; 128: the 8-phase kernel, whose
+// waves own one 32-column strip in each 128-column half of the tile)
 template <typename CT, int MODE, bool FULL>
 __device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm, int wn,
-                                         int lane, int64_t coff, int64_t roff) {
+                                         int lane, int64_t coff, int64_t roff, int jstride = 32) {
   const int li = lane & 31, lk = lane >> 5;
   constexpr bool PAIR = FULL && sizeof(CT) == 2;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 32 + li;
+      const int64_t n = n0 + wn * 64 + j * jstride + li;
       if (!FULL && n >= g.N) continue;
       const float bv = (MODE != EPI_DACT && g.bias) ? g.bias[n] : 0.f;
       float val[16], pre[16];
@@ -91,10 +93,10 @@ __device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2
 
 template <typename CT, bool FULL>
 __device__ __forceinline__ void epilogue_mode(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm,
-                                              int wn, int lane, int64_t coff, int64_t roff) {
-  if (g.mul_dact) epilogue<CT, EPI_DACT, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff);
-  else if (g.act != SEGCLIP_ACT_NONE) epilogue<CT, EPI_ACT, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff);
-  else epilogue<CT, EPI_PLAIN, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff);
+                                              int wn, int lane, int64_t coff, int64_t roff, int jstride = 32) {
+  if (g.mul_dact) epilogue<CT, EPI_DACT, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
+  else if (g.act != SEGCLIP_ACT_NONE) epilogue<CT, EPI_ACT, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
+  else epilogue<CT, EPI_PLAIN, FULL>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
 }
 
 
@@ -111,7 +113,8 @@ __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
   for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(v[j] << 16); f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u); }
 }
 
-template <typename CT, int MODE>
+// NSPLIT > 0: the sub-tile's local columns 0-31 / 32-63 live at global columns nw + 0..31 / nw + NSPLIT + 0..31.
+template <typename CT, int MODE, int NSPLIT = 0>
 __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
                                              int lane, int64_t coff, int64_t roff) {
   const int li = lane & 31, lk = lane >> 5;
@@ -127,7 +130,7 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
   constexpr int LPR = 64 / W;                      // lanes per row
   constexpr int RPI = 64 / LPR;                    // rows per iteration
   const int cl = lane % LPR, rl = lane / LPR;
-  const int64_t n = nw + cl * W;
+  const int64_t n = NSPLIT > 0 ? nw + ((cl * W) >> 5) * NSPLIT + ((cl * W) & 31) : nw + cl * W;
   float bias[W];
 #pragma unroll
   for (int c = 0; c < W; ++c) bias[c] = 0.f;
@@ -242,12 +245,12 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
   }
 }
 
-template <typename CT>
+template <typename CT, int NSPLIT = 0>
 __device__ __forceinline__ void epilogue_lds_mode(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
                                                   int64_t nw, int lane, int64_t coff, int64_t roff) {
-  if (g.mul_dact) epilogue_lds<CT, EPI_DACT>(g, acc, t, mw, nw, lane, coff, roff);
-  else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds<CT, EPI_ACT>(g, acc, t, mw, nw, lane, coff, roff);
-  else epilogue_lds<CT, EPI_PLAIN>(g, acc, t, mw, nw, lane, coff, roff);
+  if (g.mul_dact) epilogue_lds<CT, EPI_DACT, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
+  else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds<CT, EPI_ACT, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
+  else epilogue_lds<CT, EPI_PLAIN, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
 }
 
 }  // namespace

@@ -266,6 +266,9 @@ static int pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits) {
   return eff(256) >= eff(128) ? 256 : 128;
 }
 
+// tile width the dispatcher would use (the phase-pipelined 256x256 kernel of gemm_bf16_p8.hip takes the 256-wide cases)
+int segclip_gemm_bf16_dma_pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits) { return pick_bn(d, nbatch_splits); }
+
 // Launch the LDS-DMA kernel.  `args_` is prepared by the caller (gemm_bf16.hip); returns false when the shape
 // does not meet this kernel's preconditions (the caller then uses the register-staged kernel).
 bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t kper, int64_t nb,

@@ -1,0 +1,317 @@
+// bf16 MFMA GEMM, 256x256x64 tile, phase-pipelined LDS-DMA ring (the fast path for the large aligned shapes of the
+// training step; same contract as gemm_bf16_dma.hip: C[z](m,n) = epi(alpha * sum_k A(m,k) * B(n,k)), A and B bf16, each
+// k-contiguous or k-strided, K a multiple of 64).
+//
+// What bounds the older kernel (gemm_bf16_dma.hip, one barrier per K-tile): the 64 KiB DMA burst of K-tile t+1 is issued
+// after barrier t and must have landed by barrier t+1, so a K-step lasts one loaded L2->LDS round trip (1.65 us measured
+// against 1.0 us of MFMA time) and the queue drains every step.  Here the tile's operands are four 16-KiB HALF-TILES
+//      A0 = rows 0-127, A1 = rows 128-255, B0 = columns 0-127, B1 = columns 128-255     (each [128][64 k])
+// and a wave (wr = wave/4, wc = wave%4) owns a 2x2 set of 64x32 blocks: rows {h*128 + wr*64 ..+63}, columns
+// {h*128 + wc*32 ..+31}.  A K-tile is four PHASES, one C quadrant each - (A0,B0) (A0,B1) (A1,B1) (A1,B0) - so every
+// half-tile is read from LDS in exactly ONE phase (A0,B0: phase 1, B1: phase 2, A1: phase 3; phase 4 re-uses registers)
+// and its slot can be refilled two phases later.  One half-tile (2 DMA instructions per wave) is issued per phase,
+// 4-5 phases ahead of its use:
+//      phase 1: B1(t+1)   phase 2: A1(t+1)   phase 3: A0(t+2)   phase 4: B0(t+2)
+// and waited for with a COUNTED s_waitcnt vmcnt(8) one phase before its first read, so 64 KiB stay in flight across the
+// barriers at all times (2 buffers x 4 half-tiles = 128 KiB of LDS, as before).
+// The two wave groups (wr = 0 / 1; one wave of each per SIMD) run half a phase apart: while one group issues its
+// 8 MFMAs (s_setprio 1), the other issues LDS reads + DMA for its next quadrant, so the matrix pipe of every SIMD is fed
+// alternately by its two waves.  Ordering rules (MI355X guide, LDS-DMA): data is read one phase after the vmcnt that
+// retires it (wait in phase q, every wave passes a barrier, read in phase q+1); a slot is refilled >= 2 phases after
+// its last read (the reads' lgkmcnt(0) sits after the barrier that follows them).
+#include <stdlib.h>
+
+#include "gemm_bf16_common.h"
+
+namespace {
+
+constexpr int BK = 64, BT = 256, NWV = 8;
+constexpr int UNIT = 128 * BK * 2;            // one half-tile: 16 KiB
+constexpr int BUF = 4 * UNIT;                 // A0 A1 B0 B1
+constexpr int RING = 2 * BUF;                 // 128 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// Two LDS-DMA pieces (1 KiB each: lane l writes 16 B at lds + l*16) of one half-tile, issued from INLINE ASM on purpose:
+// hipcc (ROCm 7.2) tracks an outstanding __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read_b64_tr_b16 (the transpose-read builtin carries no alias
+// information), which drains the whole ring every phase - the k-strided variants of gemm_bf16_dma.hip have exactly that
+// wait in every K-step.  Hidden from the compiler, the DMA is ordered only by the counted vmcnt waits and barriers below.
+//   s_nop 4: SGPR base written by SALU -> read by VMEM; s_nop 0: M0 written by SALU -> read by the LDS-DMA.
+// M0 is not used by anything else in this kernel (no other LDS-DMA / movrel / GWS), so it is not preserved.
+__device__ __forceinline__ void dma16x2(const char* base_uniform, uint32_t off0, uint32_t off1, uint32_t lds0) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2\n\t"
+      "s_add_u32 m0, %3, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "v"(off0), "v"(off1), "s"(base_uniform), "s"(lds0)
+      : "memory", "scc");
+}
+
+// Per-lane byte offset (relative to the tile's first element of the operand) of DMA piece `idx` (1 KiB) of half-tile h.
+// k-contiguous operand X(row,k) = X[row*ld + k]: image [128 rows][128 B], piece = 8 rows, 16-B chunk ^ ((row>>1)&7).
+__device__ __forceinline__ uint32_t off_direct(int h, int idx, int lane, int64_t ld, int64_t row0, int64_t nrows) {
+  const int u = idx * 8 + (lane >> 3);
+  const int chunk = (lane & 7) ^ ((u >> 1) & 7);
+  int64_t r = row0 + h * 128 + u;
+  r = r < nrows ? r : nrows - 1;
+  return (uint32_t)(((r - row0) * ld + chunk * 8) * 2);
+}
+// k-strided operand X(row,k) = X[k*ld + row]: image [64 k][128 rows] (256-B k-rows), piece = 4 k-rows,
+// 16-B chunk (8 rows) ^ ((k&3)<<2).
+__device__ __forceinline__ uint32_t off_ks(int h, int idx, int lane, int64_t ld, int64_t row0, int64_t nrows) {
+  const int krow = idx * 4 + (lane >> 4);
+  const int chunk = (lane & 15) ^ ((krow & 3) << 2);
+  int64_t r = row0 + h * 128 + chunk * 8;
+  r = r + 8 <= nrows ? r : nrows - 8;
+  return (uint32_t)((krow * ld + (r - row0)) * 2);
+}
+
+// MFMA 32x32x16 operand fragment: lane l -> row rbase + (l&31), k = kc*16 + 8*(l>>5) .. +7
+__device__ __forceinline__ bf16x8_t frag_direct(const char* unit, int rbase, int kc, int lane) {
+  const int r = rbase + (lane & 31);
+  const int c = kc * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8_t*>(unit + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+}
+__device__ __forceinline__ bf16x8_t frag_ks(const char* unit, int rbase, int kc, int lane) {
+  const int g4 = lane >> 4, q = lane & 15;
+  const int krow = kc * 16 + 8 * (g4 >> 1) + (q >> 2);
+  const int col = rbase + 16 * (g4 & 1) + 4 * (q & 3);
+  const char* p = unit + krow * 256 + ((((col >> 3) ^ ((krow & 3) << 2))) << 4) + ((col & 7) << 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+#define P8_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
+  constexpr int LDS_BYTES = RING > NWV * EPI_WAVE_BYTES ? RING : NWV * EPI_WAVE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t n0 = (int64_t)(wg % g.nbx) * BT, m0 = (int64_t)(wg / g.nbx) * BT;
+  const int64_t z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.bsA1 + z2 * g.bsA2;
+  const bf16_t* B = g.B + z1 * g.bsB1 + z2 * g.bsB2;
+  const int64_t coff = z1 * g.bsC1 + z2 * g.bsC2;
+  const int64_t roff = z1 * g.bsR1 + z2 * g.bsR2;
+
+  const int64_t kbeg = (int64_t)blockIdx.y * g.kper;
+  const int64_t kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+  const int nk = (int)((kend - kbeg) / BK);
+
+  // uniform tile bases (bytes) + per-lane 32-bit offsets: the DMA address is SGPR base + VGPR offset
+  const char* baseA = reinterpret_cast<const char*>(A_KS ? A + kbeg * g.lda + m0 : A + m0 * g.lda + kbeg);
+  const char* baseB = reinterpret_cast<const char*>(B_KS ? B + kbeg * g.ldb + n0 : B + n0 * g.ldb + kbeg);
+  const int64_t stepA = A_KS ? (int64_t)BK * g.lda * 2 : BK * 2;   // bytes per K-tile
+  const int64_t stepB = B_KS ? (int64_t)BK * g.ldb * 2 : BK * 2;
+  uint32_t offA[2][2], offB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      offA[h][i] = A_KS ? off_ks(h, wave * 2 + i, lane, g.lda, m0, g.M) : off_direct(h, wave * 2 + i, lane, g.lda, m0, g.M);
+      offB[h][i] = B_KS ? off_ks(h, wave * 2 + i, lane, g.ldb, n0, g.N) : off_direct(h, wave * 2 + i, lane, g.ldb, n0, g.N);
+    }
+  // half-tile `u` (0: A0, 1: A1, 2: B0, 3: B1) of K-tile t -> ring buffer t&1
+  const uint32_t lds_ring = (uint32_t)(uintptr_t)((lds_void*)smem) + wave * 2048;
+  auto stage = [&](int u, int t) {
+    const uint32_t dst = lds_ring + (t & 1) * BUF + u * UNIT;
+    if (u < 2) dma16x2(baseA + (int64_t)t * stepA, offA[u][0], offA[u][1], dst);
+    else dma16x2(baseB + (int64_t)t * stepB, offB[u - 2][0], offB[u - 2][1], dst);
+  };
+
+  f32x16 acc[2][2][2];  // [A half][32-row tile][B half]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][ri][j][r] = 0.f;
+
+  // The first round of workgroups (one per CU) starts with a bounded, staggered delay so that the CUs do not all reach
+  // their store phase at the same moment in every later round (kept from gemm_bf16_dma.hip, where it measured +5..10 %).
+  if (bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
+    const long long t_tile = (long long)nk * 3000 + 20000;
+    const long long unit = t_tile / 8 < 5000 ? t_tile / 8 : 5000;
+    const long long wait = ((bid >> 3) & 7) * unit;
+    const long long t0 = clock64();
+    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+
+  // prologue: K-tile 0 completely, A0/B0 of K-tile 1 (issue order = the steady-state order A0 B0 B1 A1 A0' B0')
+  stage(0, 0);
+  stage(2, 0);
+  stage(3, 0);
+  stage(1, 0);
+  if (nk > 1) {
+    stage(0, 1);
+    stage(2, 1);
+    wait_vm<8>();
+  } else {
+    wait_vm<4>();
+  }
+  P8_BAR();
+  if (wr == 1) P8_BAR();  // group 1 runs one barrier interval behind group 0
+
+  bf16x8_t fa[2][4], fb0[4], fb1[4];
+  auto read_a = [&](const char* unit) {
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+        fa[ri][kc] = A_KS ? frag_ks(unit, wr * 64 + ri * 32, kc, lane) : frag_direct(unit, wr * 64 + ri * 32, kc, lane);
+  };
+  auto read_b = [&](const char* unit, bf16x8_t (&fb)[4]) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) fb[kc] = B_KS ? frag_ks(unit, wc * 32, kc, lane) : frag_direct(unit, wc * 32, kc, lane);
+  };
+  auto quadrant = [&](f32x16 (&c)[2][2], int j, const bf16x8_t (&fb)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri) c[ri][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ri][kc], fb[kc], c[ri][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  for (int t = 0; t < nk; ++t) {
+    const char* buf = smem + (t & 1) * BUF;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    // ---- phase 1: quadrant (A0, B0)
+    read_a(buf);
+    read_b(buf + 2 * UNIT, fb0);
+    if (n1) { stage(3, t + 1); wait_vm<8>(); } else { wait_vm<2>(); }   // retires B1(t), read in phase 2
+    P8_BAR();
+    quadrant(acc[0], 0, fb0);
+    P8_BAR();
+    // ---- phase 2: quadrant (A0, B1)
+    read_b(buf + 3 * UNIT, fb1);
+    if (n1) { stage(1, t + 1); wait_vm<8>(); } else { wait_vm<0>(); }   // retires A1(t), read in phase 3
+    P8_BAR();
+    quadrant(acc[0], 1, fb1);
+    P8_BAR();
+    // ---- phase 3: quadrant (A1, B1)
+    read_a(buf + UNIT);
+    if (n2) stage(0, t + 2);
+    P8_BAR();
+    quadrant(acc[1], 1, fb1);
+    P8_BAR();
+    // ---- phase 4: quadrant (A1, B0)
+    if (n2) { stage(2, t + 2); wait_vm<8>(); } else if (n1) { wait_vm<4>(); }   // retires A0(t+1), B0(t+1)
+    P8_BAR();
+    quadrant(acc[1], 0, fb0);
+    P8_BAR();
+  }
+  if (wr == 0) P8_BAR();  // group 0 catches up: both groups have executed the same number of barriers
+
+  const int64_t nw = n0 + wc * 32;  // this wave's first column (second strip at +128)
+  if (g.splits > 1) {
+    const int li = lane & 31, lk = lane >> 5;
+    float* slab = g.slab + ((int64_t)blockIdx.y * gridDim.z + z) * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t n = nw + j * 128 + li;
+          if (n >= g.N) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + i * 128 + wr * 64 + ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < g.M) __builtin_nontemporal_store(acc[i][ri][j][r], &slab[m * g.N + n]);
+          }
+        }
+    return;
+  }
+  const bool full = m0 + BT <= g.M && n0 + BT <= g.N;  // uniform over the workgroup
+  const bool vec = full && g.vec_epi;
+  if (vec) __syncthreads();  // every wave is done with the operand ring: the LDS is reused as 8 private patches
+  float* tp = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+  // two explicit copies (a loop over the A half would index the accumulators at run time -> scratch)
+#define P8_EPI(I)                                                                                              \
+  do {                                                                                                         \
+    const int64_t mw = m0 + (I) * 128 + wr * 64;                                                               \
+    if (vec) {                                                                                                 \
+      if (g.c_dtype == SEGCLIP_BF16) epilogue_lds_mode<bf16_t, 128>(g, acc[I], tp, mw, nw, lane, coff, roff);  \
+      else epilogue_lds_mode<float, 128>(g, acc[I], tp, mw, nw, lane, coff, roff);                             \
+    } else {                                                                                                   \
+      if (g.c_dtype == SEGCLIP_BF16) epilogue_mode<bf16_t, false>(g, acc[I], mw, nw, 0, 0, lane, coff, roff, 128); \
+      else epilogue_mode<float, false>(g, acc[I], mw, nw, 0, 0, lane, coff, roff, 128);                        \
+    }                                                                                                          \
+  } while (0)
+  P8_EPI(0);
+  __builtin_amdgcn_wave_barrier();
+  P8_EPI(1);
+#undef P8_EPI
+}
+
+}  // namespace
+
+// Launch the phase-pipelined kernel for problems tiled 256x256.  `args_` is prepared by the caller (gemm_bf16.hip);
+// returns false when the shape does not meet this kernel's preconditions.
+bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t kper, int64_t nb,
+                              hipStream_t stream) {
+  static const int disabled = [] { const char* e = getenv("SEGCLIP_GEMM_P8"); return e ? atoi(e) == 0 : 0; }();
+  if (disabled) return false;
+  Args g = *reinterpret_cast<const Args*>(args_);
+  const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
+  if (d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16) return false;
+  if (d->K % BK != 0 || kper % BK != 0 || d->K < BK) return false;
+  if (a_ks && (d->M % 8 != 0 || d->M < 8)) return false;
+  if (b_ks && (d->N % 8 != 0 || d->N < 8)) return false;
+  if (d->M < 64 || d->N <= 128) return false;
+  // 32-bit DMA offsets: 256 rows (or 64 k-rows) of the leading dimension must stay below 4 GiB
+  if ((a_ks ? 64 : 256) * (a_ks ? d->sak : d->sam) * 2 >= (int64_t)1 << 31) return false;
+  if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
+  g.nbx = (int)cdiv(d->N, BT);
+  g.nby = (int)cdiv(d->M, BT);
+  g.splits = splits;
+  g.kper = kper;
+  {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int64_t ce = d->c_dtype == SEGCLIP_BF16 ? 8 : 4, re = d->r_dtype == SEGCLIP_BF16 ? 8 : 4;
+    g.vec_epi = al(d->C) && al(d->aux) && al(d->residual) && al(d->bias) && d->ldc % ce == 0 &&
+                (!d->aux || d->ldaux % ce == 0) && (!d->residual || d->ldr % re == 0) && d->bsC1 % ce == 0 &&
+                d->bsC2 % ce == 0 && (!d->residual || (d->bsR1 % re == 0 && d->bsR2 % re == 0));
+    if (g.colsum_part && !g.vec_epi) return false;
+  }
+  dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
+  if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false>), grid, dim3(512), 0, stream, g);
+  else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, true>), grid, dim3(512), 0, stream, g);
+  else if (a_ks && b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, true>), grid, dim3(512), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false>), grid, dim3(512), 0, stream, g);
+  return true;
+}

