@@ -9,16 +9,23 @@
 // and a wave (wr = wave/4, wc = wave%4) owns a 2x2 set of 64x32 blocks: rows {h*128 + wr*64 ..+63}, columns
 // {h*128 + wc*32 ..+31}.  A K-tile is four PHASES, one C quadrant each - (A0,B0) (A0,B1) (A1,B1) (A1,B0) - so every
 // half-tile is read from LDS in exactly ONE phase (A0,B0: phase 1, B1: phase 2, A1: phase 3; phase 4 re-uses registers)
-// and its slot can be refilled two phases later.  One half-tile (2 DMA instructions per wave) is issued per phase,
-// 4-5 phases ahead of its use:
-//      phase 1: B1(t+1)   phase 2: A1(t+1)   phase 3: A0(t+2)   phase 4: B0(t+2)
-// and waited for with a COUNTED s_waitcnt vmcnt(8) one phase before its first read, so 64 KiB stay in flight across the
-// barriers at all times (2 buffers x 4 half-tiles = 128 KiB of LDS, as before).
-// The two wave groups (wr = 0 / 1; one wave of each per SIMD) run half a phase apart: while one group issues its
-// 8 MFMAs (s_setprio 1), the other issues LDS reads + DMA for its next quadrant, so the matrix pipe of every SIMD is fed
-// alternately by its two waves.  Ordering rules (MI355X guide, LDS-DMA): data is read one phase after the vmcnt that
-// retires it (wait in phase q, every wave passes a barrier, read in phase q+1); a slot is refilled >= 2 phases after
-// its last read (the reads' lgkmcnt(0) sits after the barrier that follows them).
+// and its slot can be refilled two phases later.  A phase is an R segment (LDS fragment reads, the DMA issue of one
+// half-tile = 2 instructions per wave, one counted vmcnt wait) and an M segment (8 MFMAs, s_setprio 1) separated by
+// barriers.  The two wave groups (wr = 0 / 1; one wave of each per SIMD) run half a phase apart: while one group is in
+// M the other is in R, so the matrix pipe of every SIMD is fed alternately by its two waves and the issue cost of the
+// loads (measured: ~16 cycles per ds_read_b128, ~80 per LDS-DMA piece; an in-order wave cannot hide them in its own
+// MFMA gaps - a variant with the loads inside M ran 18 % slower) is paid under the partner's MFMAs.  For that the R
+// segments must all be shorter than an M segment (256 cycles), i.e. the load work must be spread evenly:
+//      R1: read A0(t)   (8) + DMA A1(t+1)        M1: quadrant (A0,B0)
+//      R2: read B1(t)   (4) + DMA B0(t+2)        M2: quadrant (A0,B1)
+//      R3: read A1(t)   (8) + DMA A0(t+2)        M3: quadrant (A1,B1)
+//      R4: read B0(t+1) (4) + DMA B1(t+2)        M4: quadrant (A1,B0)      (the two B register sets alternate per tile)
+// Every half-tile is issued 5 phases ahead of the R segment that reads it, at the first moment its slot is free, and is
+// retired by a COUNTED s_waitcnt vmcnt(10) one phase before that read, so 80 KiB stay in flight across the barriers at
+// all times (2 buffers x 4 half-tiles = 128 KiB of LDS, as in the older kernel).
+// Ordering rules (MI355X guide, LDS-DMA): data is read one phase after the vmcnt that retires it (wait in R(q), every
+// wave passes a barrier, read in R(q+1)); a slot is refilled >= 2 phases after its last read (the reads' lgkmcnt(0) sits
+// after the barrier that follows them).
 #include <stdlib.h>
 
 #include "gemm_bf16_common.h"
@@ -97,7 +104,9 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -108,7 +117,9 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-template <bool A_KS, bool B_KS>
+// ABL (experiments, SEGCLIP_P8_ABL, k-contiguous layout only): 1 no MFMAs, 2 no DMA, 3 no LDS reads, 4 no stagger
+// between the wave groups - each leaves the rest of the schedule in place, results are garbage.
+template <bool A_KS, bool B_KS, int ABL = 0>
 __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   constexpr int LDS_BYTES = RING > NWV * EPI_WAVE_BYTES ? RING : NWV * EPI_WAVE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -145,6 +156,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   // half-tile `u` (0: A0, 1: A1, 2: B0, 3: B1) of K-tile t -> ring buffer t&1
   const uint32_t lds_ring = (uint32_t)(uintptr_t)((lds_void*)smem) + wave * 2048;
   auto stage = [&](int u, int t) {
+    if constexpr (ABL == 2) return;
     const uint32_t dst = lds_ring + (t & 1) * BUF + u * UNIT;
     if (u < 2) dma16x2(baseA + (int64_t)t * stepA, offA[u][0], offA[u][1], dst);
     else dma16x2(baseB + (int64_t)t * stepB, offB[u - 2][0], offB[u - 2][1], dst);
@@ -165,28 +177,37 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   if (bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
     const long long t_tile = (long long)nk * 3000 + 20000;
     const long long unit = t_tile / 8 < 5000 ? t_tile / 8 : 5000;
-    const long long wait = ((bid >> 3) & 7) * unit;
+    // tiles of one block row share their A rows through the XCD's L2: they get the SAME delay and stay in lockstep
+    const long long wait = ((wg / g.nbx) & 7) * unit;
     const long long t0 = clock64();
     while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
 
-  // prologue: K-tile 0 completely, A0/B0 of K-tile 1 (issue order = the steady-state order A0 B0 B1 A1 A0' B0')
-  stage(0, 0);
+  // prologue: the issue order continues into the steady state (... B0 A0 B1 A1 ...): K-tile 0 and, of K-tile 1,
+  // everything but A1 (issued in R1 of tile 0)
   stage(2, 0);
+  stage(0, 0);
   stage(3, 0);
   stage(1, 0);
   if (nk > 1) {
-    stage(0, 1);
     stage(2, 1);
-    wait_vm<8>();
+    stage(0, 1);
+    stage(3, 1);
+    wait_vm<10>();   // B0(0), A0(0) have landed
   } else {
     wait_vm<4>();
   }
   P8_BAR();
-  if (wr == 1) P8_BAR();  // group 1 runs one barrier interval behind group 0
 
-  bf16x8_t fa[2][4], fb0[4], fb1[4];
+  bf16x8_t fa[2][4], fbx[4], fby[4];
+  if constexpr (ABL == 3) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      fa[0][kc] = fa[1][kc] = fbx[kc] = fby[kc] = __builtin_bit_cast(bf16x8_t, u32x4{(unsigned)lane, 1u, 2u, 3u});
+    }
+  }
   auto read_a = [&](const char* unit) {
+    if constexpr (ABL == 3) return;
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
@@ -194,10 +215,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
         fa[ri][kc] = A_KS ? frag_ks(unit, wr * 64 + ri * 32, kc, lane) : frag_direct(unit, wr * 64 + ri * 32, kc, lane);
   };
   auto read_b = [&](const char* unit, bf16x8_t (&fb)[4]) {
+    if constexpr (ABL == 3) return;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) fb[kc] = B_KS ? frag_ks(unit, wc * 32, kc, lane) : frag_direct(unit, wc * 32, kc, lane);
   };
   auto quadrant = [&](f32x16 (&c)[2][2], int j, const bf16x8_t (&fb)[4]) {
+    if constexpr (ABL == 1) {  // keep the fragments live without issuing matrix instructions
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fa[0][kc])), "v"(__builtin_bit_cast(u32x4, fa[1][kc])),
+                     "v"(__builtin_bit_cast(u32x4, fb[kc])));
+      }
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc)
@@ -206,35 +236,46 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  for (int t = 0; t < nk; ++t) {
+  read_b(smem + 2 * UNIT, fbx);          // B0 of K-tile 0 (in the loop this read sits in R4 of the previous tile)
+  if (ABL != 4 && wr == 1) P8_BAR();     // group 1 runs one barrier interval behind group 0
+
+  // one K-tile: fbp holds B0(t) on entry and fbq is free; on exit fbq holds B0(t+1)
+  auto ktile = [&](int t, bf16x8_t (&fbp)[4], bf16x8_t (&fbq)[4]) {
     const char* buf = smem + (t & 1) * BUF;
+    const char* nbuf = smem + ((t + 1) & 1) * BUF;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
     // ---- phase 1: quadrant (A0, B0)
     read_a(buf);
-    read_b(buf + 2 * UNIT, fb0);
-    if (n1) { stage(3, t + 1); wait_vm<8>(); } else { wait_vm<2>(); }   // retires B1(t), read in phase 2
+    if (n1) { stage(1, t + 1); wait_vm<10>(); } else { wait_vm<2>(); }          // retires B1(t), read in R2
     P8_BAR();
-    quadrant(acc[0], 0, fb0);
+    quadrant(acc[0], 0, fbp);
     P8_BAR();
     // ---- phase 2: quadrant (A0, B1)
-    read_b(buf + 3 * UNIT, fb1);
-    if (n1) { stage(1, t + 1); wait_vm<8>(); } else { wait_vm<0>(); }   // retires A1(t), read in phase 3
+    read_b(buf + 3 * UNIT, fbq);
+    if (n2) { stage(2, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<8>(); } else { wait_vm<0>(); }   // retires A1(t)
     P8_BAR();
-    quadrant(acc[0], 1, fb1);
+    quadrant(acc[0], 1, fbq);
     P8_BAR();
     // ---- phase 3: quadrant (A1, B1)
     read_a(buf + UNIT);
-    if (n2) stage(0, t + 2);
+    if (n2) { stage(0, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<6>(); }   // retires B0(t+1), read in R4
     P8_BAR();
-    quadrant(acc[1], 1, fb1);
+    quadrant(acc[1], 1, fbq);
     P8_BAR();
-    // ---- phase 4: quadrant (A1, B0)
-    if (n2) { stage(2, t + 2); wait_vm<8>(); } else if (n1) { wait_vm<4>(); }   // retires A0(t+1), B0(t+1)
+    // ---- phase 4: quadrant (A1, B0); B1's registers are free: B0(t+1) goes there
+    if (n1) read_b(nbuf + 2 * UNIT, fbq);
+    if (n2) { stage(3, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<4>(); }   // retires A0(t+1), read in R1
     P8_BAR();
-    quadrant(acc[1], 0, fb0);
+    quadrant(acc[1], 0, fbp);
     P8_BAR();
+  };
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    ktile(t, fbx, fby);
+    ktile(t + 1, fby, fbx);
   }
-  if (wr == 0) P8_BAR();  // group 0 catches up: both groups have executed the same number of barriers
+  if (t < nk) ktile(t, fbx, fby);
+  if (ABL != 4 && wr == 0) P8_BAR();  // group 0 catches up: both groups have executed the same number of barriers
 
   const int64_t nw = n0 + wc * 32;  // this wave's first column (second strip at +128)
   if (g.splits > 1) {
@@ -309,7 +350,12 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
     if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
-  if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false>), grid, dim3(512), 0, stream, g);
+  static const int abl = [] { const char* e = getenv("SEGCLIP_P8_ABL"); return e ? atoi(e) : 0; }();
+  if (!a_ks && !b_ks && abl == 1) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 1>), grid, dim3(512), 0, stream, g);
+  else if (!a_ks && !b_ks && abl == 2) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 2>), grid, dim3(512), 0, stream, g);
+  else if (!a_ks && !b_ks && abl == 3) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 3>), grid, dim3(512), 0, stream, g);
+  else if (!a_ks && !b_ks && abl == 4) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 4>), grid, dim3(512), 0, stream, g);
+  else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false>), grid, dim3(512), 0, stream, g);
   else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, true>), grid, dim3(512), 0, stream, g);
   else if (a_ks && b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, true>), grid, dim3(512), 0, stream, g);
   else hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false>), grid, dim3(512), 0, stream, g);
