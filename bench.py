@@ -27,7 +27,9 @@ sys.path.insert(0, ROOT)
 import segclip_amd  # noqa: E402
 from segclip_amd import ops, synth  # noqa: E402
 
-GF_PER_PAIR_FWD_BWD = 109.675  # ViT-B/16 contrastive-only, contractions only
+# algorithmic GFLOP per image-text pair, forward+backward, contractions only
+GF_PER_PAIR = {("vitb16", False): 109.675, ("vitb16", True): 144.074, ("vitl14_336", False): 535.273}
+MODEL_NAME = {"vitb16": "ViT-B/16 224^2", "vitl14_336": "ViT-L/14 336^2 (12 blocks of width 1024, 576 patches)", "tiny": "tiny"}
 PEAK_BF16_TF = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -229,19 +231,23 @@ def main():
                     "avg_launch_us": round(tsum / len(rec) * 1e6, 1),
                     "gemm_time_per_step_ms": round(tsum * 1e3, 2),
                     "large_gemm_tflops": round(sum(r[1] for r in big) / max(sum(r[0] for r in big), 1e-9) / 1e12, 1),
-                    "step_frac": round(pairs / world * GF_PER_PAIR_FWD_BWD / 1e3 / PEAK_BF16_TF, 4)}
+                    "step_frac": (round(pairs / world * GF_PER_PAIR[(a.spec, a.full_loss)] / 1e3 / PEAK_BF16_TF, 4)
+                                  if (a.spec, a.full_loss) in GF_PER_PAIR else None)}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
-        out = {"metric": ("image-text pairs/s fwd+bwd, ViT-B/16 224^2, global batch %d (per-GPU %d)" % (a.batch * world, a.batch)
+        mname = MODEL_NAME.get(a.spec, a.spec)
+        out = {"metric": ("image-text pairs/s fwd+bwd, %s, global batch %d (per-GPU %d)" % (mname, a.batch * world, a.batch)
                           if a.global_batch else
-                          "image-text pairs/s fwd+bwd, ViT-B/16 224^2, per-GPU batch %d (global 2048 at 8 GPUs)" % a.batch),
+                          "image-text pairs/s fwd+bwd, %s, per-GPU batch %d (global %d at 8 GPUs)" % (mname, a.batch, 8 * a.batch)),
                "value": round(pairs, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
                "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": ("BASELINE configs[3]: ViT-B/16 224^2 + 77-token text, full SegCLIP loss"
+               "config": {"workload": ("BASELINE configs[4]: ViT-L/14 336^2 + 77-token text, contrastive loss only"
+                                       if a.spec == "vitl14_336" else
+                                       "BASELINE configs[3]: ViT-B/16 224^2 + 77-token text, full SegCLIP loss"
                                        if a.full_loss else
                                        "BASELINE configs[1]/[2]: ViT-B/16 224^2 + 77-token text, contrastive loss only"),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",

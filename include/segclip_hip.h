@@ -166,6 +166,10 @@ int segclip_add(const void* a, const void* b, void* out, int64_t n, int dtype, v
  * ------------------------------------------------------------------------------------------ */
 int segclip_im2col(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
                    int layout, int out_dtype, void* stream);
+/* same, with rows of `ld` >= 3*p*p elements whose tail columns are zero-filled: the contraction dimension of the
+ * patch-embedding GEMM padded to the kernel's alignment (ViT-L/14: 3*14*14 = 588 -> 640). */
+int segclip_im2col_ld(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                      int layout, int out_dtype, int64_t ld, void* stream);
 int segclip_vis_assemble(const void* patches, const float* cls, const float* pos, float* x, int64_t B,
                          int64_t T, int64_t D, int p_dtype, void* stream);
 

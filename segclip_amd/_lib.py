@@ -78,6 +78,7 @@ SIGNATURES = {
     "segclip_scale": (C.c_int, [vp, vp, vp, i64, vp]),
     "segclip_reduce_sum": (C.c_int, [vp, vp, i64, f32, vp]),
     "segclip_im2col": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_int, C.c_int, vp]),
+    "segclip_im2col_ld": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_int, C.c_int, i64, vp]),
     "segclip_vis_assemble": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_embed_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "segclip_embed_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),

@@ -457,6 +457,8 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
   }
 }
 
+#include "attention_stream.inc"
+
 // ------------------------------- f32 path helpers -------------------------------------------
 // in-place row softmax of S (rows = B*H*Tq, Tk cols), causal mask by query index row % Tq
 __global__ void softmax_rows_kernel(float* __restrict__ S, int64_t rows, int Tq, int Tk, int causal) {
@@ -509,7 +511,10 @@ extern "C" size_t segclip_attn_stats_bytes(const segclip_attn_desc* d) {
   return (size_t)d->B * d->H * d->Tq * d->Tk * sizeof(float);
 }
 extern "C" size_t segclip_attn_bwd_ws_bytes(const segclip_attn_desc* d) {
-  if (d->dtype == SEGCLIP_BF16) return 0;
+  if (d->dtype == SEGCLIP_BF16) {
+    if (d->Tq <= TMAX && d->Tk <= TMAX) return 0;
+    return (size_t)d->B * d->H * (d->Tq + d->Tk) * sizeof(float);  // streaming kernels: cs[key] and D[q]
+  }
   return (size_t)d->B * d->H * d->Tq * d->Tk * sizeof(float);
 }
 
@@ -564,8 +569,6 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     SEGCLIP_REQUIRE(bf16_ok(d), "attn_bwd bf16: head_dim and all strides must be multiples of 8");
     const int64_t s[] = {d->dq_sb, d->dq_st, d->dk_sb, d->dk_st, d->dv_sb, d->dv_st, d->do_sb, d->do_st};
     for (int64_t v : s) SEGCLIP_REQUIRE(v % 8 == 0, "attn_bwd bf16: gradient strides must be multiples of 8");
-    SEGCLIP_REQUIRE(d->Tq <= TMAX && d->Tk <= TMAX, "attn_bwd bf16: Tq=%lld Tk=%lld > %d not supported yet",
-                    (long long)d->Tq, (long long)d->Tk, TMAX);
     BwdArgs a;
     a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.V = (const bf16_t*)d->V; a.O = (const bf16_t*)d->O;
     a.dO = (const bf16_t*)d->dO; a.lse = (const float*)d->stats;
@@ -575,6 +578,30 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.o_sb = d->o_sb; a.o_st = d->o_st; a.do_sb = d->do_sb; a.do_st = d->do_st;
     a.dq_sb = d->dq_sb; a.dq_st = d->dq_st; a.dk_sb = d->dk_sb; a.dk_st = d->dk_st; a.dv_sb = d->dv_sb; a.dv_st = d->dv_st;
     a.scale = d->scale; a.causal = d->causal;
+    a.colsum_part = (float*)d->colsum_part;
+    if (d->Tq > TMAX || d->Tk > TMAX) {
+      // long sequences: two streaming launches (dK,dV | dQ), 8 owned tiles per workgroup
+      SEGCLIP_REQUIRE(d->ws != nullptr, "attn_bwd bf16: workspace required for sequences longer than %d", TMAX);
+      const size_t lds = bwd_stream_lds_bytes();
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_stream_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_stream_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SEGCLIP_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit");
+        attr_set = true;
+      }
+      const int ktiles = (int)cdiv(d->Tk, 32), qtiles = (int)cdiv(d->Tq, 32);
+      const int nwk = ktiles < 8 ? ktiles : 8, nwq = qtiles < 8 ? qtiles : 8;
+      hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel, dim3((unsigned)(d->B * d->H), (unsigned)cdiv(ktiles, nwk)),
+                         dim3(nwk * 64), lds, stream, a, (float*)d->ws);
+      SEGCLIP_CHECK_LAUNCH("attn_bwd_dkv_stream");
+      hipLaunchKernelGGL(attn_bwd_dq_stream_kernel, dim3((unsigned)(d->B * d->H), (unsigned)cdiv(qtiles, nwq)),
+                         dim3(nwq * 64), lds, stream, a, (const float*)d->ws);
+      SEGCLIP_CHECK_LAUNCH("attn_bwd_dq_stream");
+      return 0;
+    }
     const int tiles = (int)cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32);
     // 4 waves per workgroup (each wave walks over 1-2 tiles): two such workgroups fit the registers (2 waves per SIMD
     // at ~215 VGPRs) and the LDS of a CU, so their load / MFMA / store phases interleave.  SEGCLIP_ATTN_BWD_WAVES
@@ -582,7 +609,6 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     static const int force_waves = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_WAVES"); return e ? atoi(e) : 0; }();
     int nw = tiles < 4 ? tiles : 4;
     if (force_waves >= 1 && force_waves <= 8) nw = tiles < force_waves ? tiles : force_waves;
-    a.colsum_part = (float*)d->colsum_part;
     const int tp = (int)(cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32) * 32);
     const size_t lds = bwd_lds_bytes(tp);
     static bool lds_attr_set = false;

@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 mkdir -p build
 echo "$FLAGS" > build/.flags.new
 if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o; mv build/.flags.new build/.flags; else rm -f build/.flags.new; fi
-newest_hdr=$(ls -t *.h ../../include/*.h | head -1)
+newest_hdr=$(ls -t *.h *.inc ../../include/*.h | head -1)
 pids=()
 for f in gemm_f32.hip gemm_bf16.hip gemm_bf16_dma.hip gemm_bf16_p8.hip layernorm.hip attention.hip misc.hip optim.hip capi.cpp; do
   [ -f "$f" ] || continue

@@ -165,13 +165,15 @@ __global__ void interp_bicubic_kernel(const float* __restrict__ src, float* __re
 
 // ---------------------------------------------------------------- vision front end
 // layout 0: col = c*p*p + py*p + px (conv1 weight order) ; layout 1: col = (py*p + px)*C + c (MAE patchify)
+// rows of `ld` >= C*p*p elements; columns beyond C*p*p are zero (K padded to the GEMM's alignment, e.g. 3*14*14 = 588 -> 640)
 __global__ void im2col_kernel(const float* __restrict__ img, void* __restrict__ cols, int64_t B, int C, int H, int W,
-                              int p, int layout, int od) {
+                              int p, int layout, int od, int64_t ld) {
   const int gw = W / p, gh = H / p;
-  const int64_t kdim = (int64_t)C * p * p, total = B * gh * gw * kdim;
+  const int64_t kdim = (int64_t)C * p * p, total = B * gh * gw * ld;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / kdim;
-    const int col = (int)(i % kdim);
+    const int64_t row = i / ld;
+    const int col = (int)(i % ld);
+    if (col >= kdim) { stx(cols, od, i, 0.f); continue; }
     int c, py, px;
     if (layout == 0) { c = col / (p * p); py = (col / p) % p; px = col % p; }
     else { c = col % C; py = (col / C) / p; px = (col / C) % p; }
@@ -518,16 +520,21 @@ extern "C" int segclip_colsum(const void* X, float* out, void* ws, int64_t M, in
   SEGCLIP_CHECK_LAUNCH("colsum_final");
   return 0;
 }
-extern "C" int segclip_im2col(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
-                              int layout, int od, void* stream) {
+extern "C" int segclip_im2col_ld(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                                 int layout, int od, int64_t ld, void* stream) {
   SEGCLIP_REQUIRE(H % p == 0 && W % p == 0, "im2col: %lldx%lld not divisible by patch %lld", (long long)H, (long long)W,
                   (long long)p);
-  const int64_t total = B * C * H * W;
+  SEGCLIP_REQUIRE(ld >= C * p * p, "im2col: ld=%lld < C*p*p=%lld", (long long)ld, (long long)(C * p * p));
+  const int64_t total = B * (H / p) * (W / p) * ld;
   if (total == 0) return 0;
   hipLaunchKernelGGL(im2col_kernel, dim3(grid1d(total)), dim3(TPB), 0, ST, image, cols, B, (int)C, (int)H, (int)W, (int)p,
-                     layout, od);
+                     layout, od, ld);
   SEGCLIP_CHECK_LAUNCH("im2col");
   return 0;
+}
+extern "C" int segclip_im2col(const float* image, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                              int layout, int od, void* stream) {
+  return segclip_im2col_ld(image, cols, B, C, H, W, p, layout, od, C * p * p, stream);
 }
 extern "C" int segclip_vis_assemble(const void* patches, const float* cls, const float* pos, float* x, int64_t B, int64_t T,
                                     int64_t D, int pd, void* stream) {

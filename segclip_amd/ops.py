@@ -627,7 +627,9 @@ class PatchEmbedFn(Function):
     """conv1 (16x16/16, no bias) as im2col + GEMM with the positional table fused as the epilogue
     residual (modules/module_clip_vtransformer.py:56-64).  The CLS row the reference prepends is
     discarded by SegViT before any use (modules/module_seg_vit.py:419), so it is never materialised;
-    class_embedding therefore receives an all-zero gradient, exactly as in the reference."""
+    class_embedding therefore receives an all-zero gradient, exactly as in the reference.
+    bf16 mode pads the contraction dimension 3*p*p to a multiple of 64 with zero columns (ViT-L/14: 588 -> 640) so
+    that the patch GEMM runs on the LDS-DMA kernels."""
 
     @staticmethod
     def forward(ctx, image, conv_w, cls, pos, patch, act_dtype):
@@ -636,26 +638,32 @@ class PatchEmbedFn(Function):
         D = conv_w.shape[0]
         T = (H // patch) * (W // patch)
         Kd = Cc * patch * patch
+        Kp = Kd if (act_dtype != torch.bfloat16 or Kd % 64 == 0) else -(-Kd // 64) * 64
         image = image.contiguous()
-        cols = _empty((B * T, Kd), act_dtype, image)
-        L.check(lib.segclip_im2col(L.ptr(image), L.ptr(cols), B, Cc, H, W, patch, 0, L.dt(cols), L.stream()), "im2col")
-        wc = wcast(conv_w.reshape(D, Kd), act_dtype)
+        cols = _empty((B * T, Kp), act_dtype, image)
+        L.check(lib.segclip_im2col_ld(L.ptr(image), L.ptr(cols), B, Cc, H, W, patch, 0, L.dt(cols), Kp, L.stream()), "im2col")
+        if Kp == Kd:
+            wc = wcast(conv_w.reshape(D, Kd), act_dtype)
+        else:
+            wc = torch.zeros((D, Kp), dtype=act_dtype, device=image.device)
+            wc[:, :Kd] = p_cast(conv_w.detach().reshape(D, Kd).contiguous(), act_dtype)
         x = _empty((B, T, D), torch.float32, image)
         posc = pos.detach().contiguous()
-        p_gemm(cols, wc, x, T, D, Kd, (Kd, 1), (Kd, 1), D, residual=posc, ldr=D, r_off=D, nb1=B, bsA=(T * Kd, 0),
+        p_gemm(cols, wc, x, T, D, Kp, (Kp, 1), (Kp, 1), D, residual=posc, ldr=D, r_off=D, nb1=B, bsA=(T * Kp, 0),
                bsC=(T * D, 0), bsR=(0, 0))
         ctx.save_for_backward(cols)
-        ctx.shape = (B, T, D, Kd, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape))
+        ctx.shape = (B, T, D, Kd, Kp, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape))
         return x
 
     @staticmethod
     def backward(ctx, dx):
         (cols,) = ctx.saved_tensors
-        B, T, D, Kd, wshape, cshape, pshape = ctx.shape
+        B, T, D, Kd, Kp, wshape, cshape, pshape = ctx.shape
         dx = dx.contiguous()
         dw = dcls = dpos = None
         if ctx.needs_input_grad[1]:
-            dw = p_wgrad(dx.view(B * T, D), cols).view(wshape)
+            dw = p_wgrad(dx.view(B * T, D), cols)
+            dw = (dw if Kp == Kd else dw[:, :Kd].contiguous()).view(wshape)
         if ctx.needs_input_grad[2]:
             dcls = torch.zeros(cshape, dtype=torch.float32, device=dx.device)
         if ctx.needs_input_grad[3]:

@@ -160,7 +160,9 @@ def _attn_ref(q, k, v, H, causal):
 @pytest.mark.parametrize("dtype", [F32, BF])
 @pytest.mark.parametrize("B,T,H,hd,causal", [(2, 196, 12, 64, False), (3, 77, 8, 64, True), (2, 8, 2, 64, False),
                                              (2, 197, 8, 48, False), (2, 17, 8, 8, False), (1, 48, 12, 64, False),
-                                             (2, 256, 2, 64, True)])
+                                             (2, 256, 2, 64, True),
+                                             # > 256 tokens: the streaming backward (ViT-L/14 at 336^2: 576 patches)
+                                             (2, 576, 16, 64, False), (1, 300, 2, 64, True), (1, 784, 3, 64, False)])
 def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
     """Packed-QKV self attention exactly as ResBlockFn drives it (forward + backward)."""
     D = H * hd
@@ -191,7 +193,7 @@ def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
 
 @pytest.mark.parametrize("dtype", [F32, BF])
 @pytest.mark.parametrize("mode", ["t18", "intended"])
-@pytest.mark.parametrize("B,G,T,H", [(4, 8, 196, 12), (3, 8, 48, 2)])
+@pytest.mark.parametrize("B,G,T,H", [(4, 8, 196, 12), (3, 8, 48, 2), (2, 8, 576, 16)])
 def test_cross_attention_both_layouts(dtype, mode, B, G, T, H):
     """Center cross-attention with the torch-1.8 key-buffer reinterpretation and the intended layout."""
     D, S = H * 64, G + T

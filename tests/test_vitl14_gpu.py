@@ -1,0 +1,69 @@
+"""GPU: BASELINE.json configs[4] shape - "ViT-L/14" widths at 336^2 (conv1 (1024,3,14,14), 576 patch
+tokens + CLS, 16 heads, text width 768; SegViT still builds 10+2 blocks) - through the product path:
+ * exact-f32 mode against the CPU oracle on the same seeded inputs (loss / logits 1e-3, hard_idx bit-exact);
+ * bf16 mode against the f32 run (bounded);
+exercising the streaming attention backward (576 > 256 tokens), the zero-padded patch GEMM (3*14*14 = 588 -> 640) and
+the 584-key center cross-attention."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import segclip_amd  # noqa: E402
+from segclip_amd import synth  # noqa: E402
+
+DEV = "cuda"
+
+
+def _run(dtype, B, seed):
+    spec = synth.SPECS["vitl14_336"]
+    segclip_amd.set_compute_dtype(dtype)
+    try:
+        model, _ = synth.build_model(spec, {}, device=DEV)
+        batch = synth.synthetic_batch(spec, B, seed=seed, device=DEV, with_seg=False)
+        noise = synth.synthetic_noise(spec, B, seed=seed, device=DEV)
+        with segclip_amd.noise_injection([("gumbel", noise["gumbel_main"])]):
+            loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"])
+        loss.backward()
+        torch.cuda.synchronize()
+        out = dict(loss=float(loss.detach()), t2v=model.last_logits[0].float().cpu(),
+                   hard_idx=model.last_mid_states["hard_idx"].cpu().long(),
+                   gn={n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None})
+        del model
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
+
+
+def test_vitl14_336_f32_matches_oracle_and_bf16_is_bounded():
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["vitl14_336"]
+    B, seed = 2, 5
+    f = _run(torch.float32, B, seed)
+    P = oracle_params(spec, model_param_shapes(spec, {}))
+    lo, aux = so.segclip_forward(synth.synthetic_batch(spec, B, seed=seed, with_seg=False), P, spec,
+                                 synth.synthetic_noise(spec, B, seed=seed), {})
+    lo.backward()
+    assert f["hard_idx"].shape == (B, 576)
+    assert abs(f["loss"] - float(lo)) <= 1e-3, (f["loss"], float(lo))
+    assert float((f["t2v"] - aux["t2v"].detach()).abs().max()) <= 1e-3
+    assert torch.equal(f["hard_idx"], aux["hard_idx"])
+    worst = 0.0
+    for n, p in P.items():
+        if p.grad is None or n not in f["gn"]:
+            continue
+        ref = float(p.grad.double().norm())
+        if ref > 1e-7:
+            worst = max(worst, abs(f["gn"][n] - ref) / ref)
+            assert abs(f["gn"][n] - ref) <= 2e-2 * ref + 1e-8, (n, f["gn"][n], ref)
+    b = _run(torch.bfloat16, B, seed)
+    dl, dlog = abs(b["loss"] - f["loss"]), float((b["t2v"] - f["t2v"]).abs().max())
+    agree = float((b["hard_idx"] == f["hard_idx"]).float().mean())
+    rat = [b["gn"][n] / f["gn"][n] for n in f["gn"] if f["gn"][n] > 1e-6]
+    print(f"\n[vitl14_336 B={B}] f32 vs oracle: worst grad-norm rel err {worst:.2e}; bf16 vs f32: d loss {dl:.2e}, "
+          f"max |dlogit| {dlog:.4f}, hard_idx agreement {agree:.4f}, grad-norm ratio median {np.median(rat):.4f}")
+    assert dl <= 0.02 and dlog <= 0.15 and agree >= 0.97
+    assert 0.95 <= float(np.median(rat)) <= 1.05
