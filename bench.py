@@ -50,6 +50,8 @@ def parse():
                     help="take the N>1 code path (RCCL group, GradSync, barriers) even with one rank: single-GPU check of it")
     ap.add_argument("--grad-sync", default="segclip", choices=["segclip", "ddp"],
                     help="N>1 gradient exchange: segclip_amd.dist.GradSync (default) or torch DDP (comparison only)")
+    ap.add_argument("--attn-fp8", default="auto", choices=["auto", "on", "off"],
+                    help="e4m3 MFMA for QK^T / PV in the self-attention forward (auto: on for --spec vitl14_336 = configs[4])")
     ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format")
     return ap.parse_args()
 
@@ -152,6 +154,8 @@ def main():
     spec = synth.SPECS[a.spec]
     flags = dict(use_seglabel=True, use_vision_mae_recon=True) if a.full_loss else {}
     segclip_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    attn_fp8 = a.dtype == "bf16" and (a.attn_fp8 == "on" or (a.attn_fp8 == "auto" and a.spec == "vitl14_336"))
+    segclip_amd.config.attn_fp8 = attn_fp8
     torch.manual_seed(1234 + rank)
     model, targs = synth.build_model(spec, flags, rank=rank, world_size=world, device=dev)
     # the reference driver freezes these two (main_task_align.py:436-441)
@@ -251,6 +255,7 @@ def main():
                                        if a.full_loss else
                                        "BASELINE configs[1]/[2]: ViT-B/16 224^2 + 77-token text, contrastive loss only"),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "attention_forward": ("fp8 e4m3 MFMA (QK^T, PV), per-token Q/K scales" if attn_fp8 else a.dtype),
                           "grad_exchange": (None if not multi else "torch DDP fp32" if a.grad_sync == "ddp" else
                                             f"GradSync {len(net._flat)} buckets, wire " +
                                             ("bf16" if net._flat and net._use_bf16(net._flat[0]) else "fp32") +

@@ -112,8 +112,10 @@ int segclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, con
  * Element strides: *_sb batch, *_st token; head h lives at offset h*hd.
  * stats: fp32 scratch kept for backward, segclip_attn_stats_bytes() bytes
  *        (bf16: log-sum-exp per row; f32: the full probability matrix).
- * bwd ws: segclip_attn_bwd_ws_bytes() bytes.
+ * bwd ws: segclip_attn_bwd_ws_bytes() bytes (f32: dP; bf16 with more than 256 tokens: the streaming kernels' D and
+ *         column-sum vectors; 0 otherwise).
  * ------------------------------------------------------------------------------------------ */
+#define SEGCLIP_ATTN_FP8 1
 typedef struct segclip_attn_desc {
   const void* Q;
   const void* K;
@@ -131,7 +133,9 @@ typedef struct segclip_attn_desc {
   float scale;
   int32_t causal;
   int32_t dtype;
-  int32_t reserved;
+  /* SEGCLIP_ATTN_FP8 (bf16 dtype, forward only): Q K^T and P V on the e4m3 MFMA (per-token scales for Q and K, one
+   * scale per 256-key chunk for V, P x 256); the statistics it leaves serve the bf16 backward.  BASELINE configs[4]. */
+  int32_t flags;
   /* bwd, bf16 only, nullable: fp32 [B][3][H*hd] receives, per sample, the token sums of dQ | dK | dV
    * (= that sample's contribution to the in_proj bias gradient of nn.MultiheadAttention), computed from the
    * tiles already in LDS instead of a separate column-sum pass over dQ/dK/dV. */

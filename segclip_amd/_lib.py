@@ -11,6 +11,7 @@ import torch
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
+ATTN_FP8 = 1
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsegclip_hip.so")
 _lib = None
@@ -53,7 +54,7 @@ class AttnDesc(C.Structure):
                 ("o_sb", i64), ("o_st", i64),
                 ("dq_sb", i64), ("dq_st", i64), ("dk_sb", i64), ("dk_st", i64), ("dv_sb", i64), ("dv_st", i64),
                 ("do_sb", i64), ("do_st", i64),
-                ("scale", f32), ("causal", i32), ("dtype", i32), ("reserved", i32), ("colsum_part", vp)]
+                ("scale", f32), ("causal", i32), ("dtype", i32), ("flags", i32), ("colsum_part", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/segclip_hip.h

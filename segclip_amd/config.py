@@ -16,6 +16,8 @@ overlap_towers: enqueue the text tower on a second HIP stream (concurrent with t
 trust_weight_shadows : False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
                 True: only weights whose autograd version changed (set per model by train.prep_optimizer when the
                 fused optimizer maintains the bf16 copies itself)
+attn_fp8      : bf16 mode only: the self-attention FORWARD of the residual blocks runs Q K^T and P V on the e4m3 MFMA
+                (BASELINE configs[4]; per-token scales for Q/K, per-chunk scale for V); backward stays bf16
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -28,7 +30,7 @@ import types
 import torch
 
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
-                 trust_weight_shadows=False)
+                 trust_weight_shadows=False, attn_fp8=False)
 _tls = threading.local()
 
 

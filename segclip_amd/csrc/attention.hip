@@ -458,6 +458,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 }
 
 #include "attention_stream.inc"
+#include "attention_fp8.inc"
 
 // ------------------------------- f32 path helpers -------------------------------------------
 // in-place row softmax of S (rows = B*H*Tq, Tk cols), causal mask by query index row % Tq
@@ -534,6 +535,12 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     const int tiles = (int)cdiv(d->Tq, 32);
     const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
     SEGCLIP_REQUIRE(d->B * d->H <= 65535, "attn_fwd: B*H too large");
+    if (d->flags & SEGCLIP_ATTN_FP8) {
+      hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3((unsigned)cdiv(tiles, nw), (unsigned)(d->B * d->H)), dim3(nw * 64), 0,
+                         stream, a);
+      SEGCLIP_CHECK_LAUNCH("attn_fwd_fp8");
+      return 0;
+    }
     hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3((unsigned)cdiv(tiles, nw), (unsigned)(d->B * d->H)), dim3(nw * 64), 0,
                        stream, a);
     SEGCLIP_CHECK_LAUNCH("attn_fwd_bf16");

@@ -35,10 +35,11 @@ _NO_EXCHANGE = bool(int(os.environ.get("SEGCLIP_GRADSYNC_NOEXCHANGE", "0")))  # 
 
 class _Slot:
     """A parameter's place in a flat gradient bucket."""
-    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner")
+    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner", "taken_pass")
 
     def __init__(self, bucket, offset, p, owner):
         self.bucket, self.offset, self.numel, self.shape = bucket, offset, p.numel(), tuple(p.shape)
+        self.taken_pass = -1
         self.param = weakref.ref(p)
         self.owner = weakref.ref(owner)
 
@@ -48,10 +49,13 @@ class _Slot:
 
     def out_buffer(self):
         """Fresh view to be used as the OUTPUT of a gradient kernel, or None when the parameter already
-        holds a gradient (accumulation: autograd must add, not alias) or the owner is not ready."""
+        holds a gradient (accumulation: autograd must add, not alias), when the slot was already handed out in this
+        backward pass (a parameter used twice - e.g. the vision tower's second, MAE pass - gets two contributions
+        that autograd sums: they must not share memory), or when the owner is not ready."""
         o, p = self.owner(), self.param()
-        if o is None or p is None or not o._steady or p.grad is not None:
+        if o is None or p is None or not o._steady or p.grad is not None or self.taken_pass == o._pass_id:
             return None
+        self.taken_pass = o._pass_id
         return self.view()
 
 
@@ -74,6 +78,7 @@ class GradSync(nn.Module):
         self._pending, self._next_bucket, self._launched, self._late, self._ready = [], 0, [], [], []
         self._bstreams = []          # per bucket: the streams its gradients were produced on in this pass
         self._comm = None
+        self._pass_id = 0
         self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0}
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
 
@@ -210,6 +215,7 @@ class GradSync(nn.Module):
         self._reset_pass()
 
     def _reset_pass(self):
+        self._pass_id += 1
         self._pending = [len(ps) for ps in self._bucket_params]
         self._ready = [False] * len(self._flat)
         self._bstreams = [set() for _ in self._flat]

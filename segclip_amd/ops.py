@@ -231,8 +231,9 @@ def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, wa
     return tuple(out)
 
 
-def _attn_desc(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, scale, causal, q_off=0, k_off=0, v_off=0):
+def _attn_desc(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, scale, causal, q_off=0, k_off=0, v_off=0, fp8=False):
     d = L.AttnDesc()
+    d.flags = L.ATTN_FP8 if fp8 else 0
     d.Q, d.K, d.V, d.O = _off(q, q_off), _off(k, k_off), _off(v, v_off), L.ptr(o)
     d.B, d.H, d.Tq, d.Tk, d.hd = B, H, Tq, Tk, hd
     d.q_sb, d.q_st = qs
@@ -504,8 +505,10 @@ class ResBlockFn(Function):
         wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (wqkv, wo, wfc, wpr))
         qkv, _ = p_linear(y1, wqkv_c, bqkv)
         o = _empty((M, D), act_dtype, x)
+        from . import config as _cfg
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, (T * 3 * D, 3 * D), (T * 3 * D, 3 * D),
-                        (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D)
+                        (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D,
+                        fp8=bool(_cfg.attn_fp8) and act_dtype == torch.bfloat16)
         stats = p_attn_fwd(ad, x)
         x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
         y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)

@@ -16,9 +16,10 @@ from segclip_amd import synth  # noqa: E402
 DEV = "cuda"
 
 
-def _run(dtype, B, seed):
+def _run(dtype, B, seed, attn_fp8=False):
     spec = synth.SPECS["vitl14_336"]
     segclip_amd.set_compute_dtype(dtype)
+    segclip_amd.config.attn_fp8 = attn_fp8
     try:
         model, _ = synth.build_model(spec, {}, device=DEV)
         batch = synth.synthetic_batch(spec, B, seed=seed, device=DEV, with_seg=False)
@@ -35,6 +36,7 @@ def _run(dtype, B, seed):
         return out
     finally:
         segclip_amd.set_compute_dtype(torch.float32)
+        segclip_amd.config.attn_fp8 = False
 
 
 def test_vitl14_336_f32_matches_oracle_and_bf16_is_bounded():
@@ -67,3 +69,12 @@ def test_vitl14_336_f32_matches_oracle_and_bf16_is_bounded():
           f"max |dlogit| {dlog:.4f}, hard_idx agreement {agree:.4f}, grad-norm ratio median {np.median(rat):.4f}")
     assert dl <= 0.02 and dlog <= 0.15 and agree >= 0.97
     assert 0.95 <= float(np.median(rat)) <= 1.05
+    # BASELINE configs[4] proper: the e4m3 QK^T / PV forward in every self-attention block
+    e = _run(torch.bfloat16, B, seed, attn_fp8=True)
+    dl8, dlog8 = abs(e["loss"] - f["loss"]), float((e["t2v"] - f["t2v"]).abs().max())
+    agree8 = float((e["hard_idx"] == f["hard_idx"]).float().mean())
+    rat8 = [e["gn"][n] / f["gn"][n] for n in f["gn"] if f["gn"][n] > 1e-6]
+    print(f"[vitl14_336 B={B}] bf16 + fp8 attention forward vs f32: d loss {dl8:.2e}, max |dlogit| {dlog8:.4f}, hard_idx "
+          f"agreement {agree8:.4f}, grad-norm ratio median {np.median(rat8):.4f}")
+    assert dl8 <= 0.05 and dlog8 <= 0.5 and agree8 >= 0.9
+    assert 0.9 <= float(np.median(rat8)) <= 1.1
