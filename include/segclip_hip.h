@@ -140,6 +140,11 @@ typedef struct segclip_attn_desc {
    * (= that sample's contribution to the in_proj bias gradient of nn.MultiheadAttention), computed from the
    * tiles already in LDS instead of a separate column-sum pass over dQ/dK/dV. */
   void* colsum_part;
+  /* nullable: int32 [B] number of valid keys per sample (keys >= klen[b] are masked out).  The key-padding mask of the
+   * text-MAE decoder blocks, modules/module_mae.py:213-219: (1 - attention_mask) * -1e6 added to the logits, where
+   * attention_mask is a prefix mask (captions are padded at the end) and exp(-1e6) == 0 in fp32.  Sequences of at most
+   * 256 keys. */
+  const int32_t* klen;
 } segclip_attn_desc;
 
 size_t segclip_attn_stats_bytes(const segclip_attn_desc* d);
@@ -233,6 +238,15 @@ int segclip_ce_fwd(const float* logits, float* lse, float* loss_rows, int64_t ro
  * gradient) may be NULL */
 int segclip_ce_bwd(const float* logits, const float* lse, const float* gscale_ptr, float gscale,
                    float* dlogits, int64_t rows, int64_t cols, int64_t label_offset, void* stream);
+/* nn.CrossEntropyLoss(ignore_index) with explicit labels (text-MAE vocabulary loss, modules/module_mae.py:353):
+ * fwd: lse[r], loss_rows[r] = (labels[r] == ignore ? 0 : lse[r] - logits[r][labels[r]]), valid[r] = labels[r] != ignore
+ *      (the mean over valid rows is taken by the caller: sum(loss_rows) / sum(valid));
+ * bwd: dlogits[r][c] = (labels[r] == ignore ? 0 : softmax[r][c] - [c == labels[r]]) * gscale[0] * inv_count[0]. */
+int segclip_ce_labels_fwd(const float* logits, const int64_t* labels, int64_t ignore_index, float* lse, float* loss_rows,
+                          float* valid, int64_t rows, int64_t cols, void* stream);
+int segclip_ce_labels_bwd(const float* logits, const float* lse, const int64_t* labels, int64_t ignore_index,
+                          const float* gscale, const float* inv_count, float* dlogits, int64_t rows, int64_t cols,
+                          void* stream);
 /* loss_rows[b] = this image's share of the loss (already / (2*B*T*G)); dhard = d(sum loss_rows)/dhard */
 int segclip_superpixel_kl(const float* hard, const int64_t* seg, float* loss_rows, float* dhard,
                           int64_t B, int64_t G, int64_t T, void* stream);

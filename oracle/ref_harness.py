@@ -142,7 +142,7 @@ def build_reference_model(spec, flags, rank=0, world_size=1, cross_mode="t18"):
     args = argparse.Namespace(local_rank=0, rank=rank, world_size=world_size,
                               pretrained_clip_name="ViT-B/16", first_stage_layer=10,
                               use_vision_mae_recon=flags.get("use_vision_mae_recon", False),
-                              use_text_mae_recon=False,
+                              use_text_mae_recon=flags.get("use_text_mae_recon", False),
                               use_seglabel=flags.get("use_seglabel", False),
                               mae_vis_mask_ratio=0.75, max_words=spec["context_length"])
     model = ns.SegCLIP.from_pretrained(cache_dir=None, state_dict=None, task_config=args)

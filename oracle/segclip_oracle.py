@@ -41,7 +41,7 @@ def gelu_erf(x):
     return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def mha_core(q, k, v, n_head, causal=False):
+def mha_core(q, k, v, n_head, causal=False, key_mask=None):
     """softmax(q k^T / sqrt(hd)) v per head.  q (B,Tq,D), k/v (B,Tk,D) already projected.
     Restates nn.MultiheadAttention's core as used at modules/module_seg_vit.py:189 and
     modules/module_clip_ttransformer.py:46 (additive -inf upper-triangular mask from
@@ -56,6 +56,8 @@ def mha_core(q, k, v, n_head, causal=False):
     if causal:
         mask = torch.full((Tq, Tk), float("-inf"), dtype=s.dtype).triu_(1)
         s = s + mask
+    if key_mask is not None:   # (B, Tk) 1 = attend: additive (1 - mask) * -1e6 (modules/module_mae.py:216-219)
+        s = s + ((1.0 - key_mask.to(s.dtype)) * -1000000.0)[:, None, None, :]
     p = torch.softmax(s, dim=-1)
     o = p @ vh
     return o.permute(0, 2, 1, 3).reshape(B, Tq, D)
@@ -275,6 +277,80 @@ def encode_text(ids, P, spec):
     return hidden[torch.arange(hidden.shape[0]), eot], hidden, eot
 
 
+def random_masking_text(x, noise, mask_ratio, sep_pos):
+    """modules/module_clip_util.py:91-124 with keep_cls=True, keep_sep=True as CLIP.encode_text calls it
+    (modules/module_clip.py:118-120).  `noise.scatter_(dim=1, index=sep_pos.unsqueeze(0), value=-1)` receives a
+    (1, N) index, so it pins the separator positions OF EVERY SAMPLE in ROW 0 only - restated as written."""
+    N, L, D = x.shape
+    len_keep = int(L * (1 - mask_ratio))
+    noise = noise.clone()
+    noise[:, 0] = -1.0
+    noise[0, sep_pos] = -1.0
+    ids_shuffle = torch.argsort(noise, dim=1, stable=True)   # torch's CPU sort is stable: ties keep index order
+    ids_restore = torch.argsort(ids_shuffle, dim=1, stable=True)
+    ids_keep = ids_shuffle[:, :len_keep]
+    x_masked = torch.gather(x, 1, ids_keep.unsqueeze(-1).repeat(1, 1, D))
+    mask = torch.ones(N, L, dtype=x.dtype)
+    mask[:, :len_keep] = 0
+    mask = torch.gather(mask, 1, ids_restore)
+    return x_masked, mask, ids_restore, ids_keep
+
+
+def encode_text_masked(ids, P, spec, noise, mask_ratio):
+    """CLIP.encode_text(return_hidden=True, mask_ratio>0), modules/module_clip.py:105-143: the kept tokens run through
+    the causal text tower IN SHUFFLED ORDER (ids_keep is not sorted), the pooled row is the argmax of the gathered ids."""
+    Wt = spec["text_width"]
+    n_head = Wt // 64
+    x = P["clip.token_embedding.weight"][ids] + P["clip.positional_embedding"][: ids.shape[1]]
+    x, mask, ids_restore, ids_keep = random_masking_text(x, noise, mask_ratio, ids.argmax(dim=-1))
+    text = torch.gather(ids, 1, ids_keep)
+    for i in range(spec["text_layers"]):
+        x = residual_attention_block(x, P, f"clip.transformer.resblocks.{i}.", n_head, causal=True)
+    hidden = layer_norm(x, P["clip.ln_final.weight"], P["clip.ln_final.bias"]) @ P["clip.text_projection"]
+    return hidden[torch.arange(hidden.shape[0]), text.argmax(dim=-1)], hidden, mask, ids_restore
+
+
+def position_encoding_init(n_position, d):
+    """modules/module_mae.py:44-54 (row 0 all zeros, sin on even / cos on odd columns, exponent 2*i/d per COLUMN i)."""
+    pos = torch.arange(n_position, dtype=torch.float64)[:, None]
+    i = torch.arange(d, dtype=torch.float64)[None, :]
+    enc = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2 * i / d)
+    out = enc.clone()
+    out[1:, 0::2] = torch.sin(enc[1:, 0::2])
+    out[1:, 1::2] = torch.cos(enc[1:, 1::2])
+    out[0] = 0
+    return out.float()
+
+
+def text_mae_loss(ids, seq_hidden, mae_mask, ids_restore, attention_mask, P, n_head=8):
+    """modules/modeling.py:226-236 + MAEDecoder.forward_seq, modules/module_mae.py:332-355; decoder blocks =
+    modules/module_mae.py:203-232 (nn.MultiheadAttention with the additive key-padding mask, erf-GELU Mlp, LN 1e-5)."""
+    M = "seq_mae_decoder."
+    x = seq_hidden @ P[M + "decoder_embed.weight"].t() + P[M + "decoder_embed.bias"]
+    B, K, Dd = x.shape
+    L = ids_restore.shape[1]
+    mtok = P[M + "mask_token"].reshape(1, 1, Dd).expand(B, L - K, Dd)
+    x = torch.gather(torch.cat([x, mtok], dim=1), 1, ids_restore.unsqueeze(-1).repeat(1, 1, Dd))
+    x = x + P[M + "decoder_pos_embed"].reshape(1, L, Dd)
+    i = 0
+    while (M + f"decoder_blocks.{i}.norm1.weight") in P:
+        pre = M + f"decoder_blocks.{i}."
+        y = layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"])
+        qkv = y @ P[pre + "attn.in_proj_weight"].t() + P[pre + "attn.in_proj_bias"]
+        q, k, v = qkv.split(Dd, dim=-1)
+        o = mha_core(q, k, v, n_head, key_mask=attention_mask)
+        x = x + (o @ P[pre + "attn.out_proj.weight"].t() + P[pre + "attn.out_proj.bias"])
+        z = layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
+        h = gelu_erf(z @ P[pre + "mlp.fc1.weight"].t() + P[pre + "mlp.fc1.bias"])
+        x = x + (h @ P[pre + "mlp.fc2.weight"].t() + P[pre + "mlp.fc2.bias"])
+        i += 1
+    x = layer_norm(x, P[M + "decoder_norm.weight"], P[M + "decoder_norm.bias"])
+    pred = x @ P[M + "decoder_pred.weight"].t() + P[M + "decoder_pred.bias"]
+    m = ((mae_mask + attention_mask.to(mae_mask.dtype)) > 1).reshape(-1).to(ids.dtype)   # masked AND not padding
+    labels = ids.reshape(-1) * m - (1 - m)
+    return torch.nn.functional.cross_entropy(pred.reshape(-1, pred.shape[-1]), labels, ignore_index=-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------------------------
@@ -373,7 +449,7 @@ def mae_decoder_loss(image, vis_hidden, mask, ids_restore, P, spec, n_head=8):
 # SegCLIP.forward (training)
 # ----------------------------------------------------------------------------------------------
 def segclip_forward(batch, P, spec, noise, flags, rank=0, gather=None, cross_mode="t18"):
-    """SegCLIP.forward in training mode, modules/modeling.py:174-256 (text-MAE branch out of scope).
+    """SegCLIP.forward in training mode, modules/modeling.py:174-256 (incl. the text-MAE branch :226-236).
     Returns (loss, aux) where aux holds every intermediate the parity tests compare."""
     ids = batch["input_ids"].reshape(-1, batch["input_ids"].shape[-1])
     image = batch["image"].float()[:, 0]
@@ -392,6 +468,13 @@ def segclip_forward(batch, P, spec, noise, flags, rank=0, gather=None, cross_mod
         l_kl = superpixel_kl(mid["attns"][0]["hard_attn"], batch["image_seg"][:, 0])
         loss = loss + l_kl
         aux["loss_kl"] = l_kl
+    if flags.get("use_text_mae_recon", False):
+        amask = batch["input_mask"].reshape(-1, batch["input_mask"].shape[-1])
+        _, s_hidden, s_mask, s_restore = encode_text_masked(ids, P, spec, noise["text_mask_noise"],
+                                                            flags.get("mae_seq_mask_ratio", 0.15))
+        l_seq = text_mae_loss(ids, s_hidden, s_mask, s_restore, amask, P)
+        loss = loss + l_seq
+        aux.update(loss_text_mae=l_seq, text_mae_mask=s_mask, text_ids_restore=s_restore, text_mae_hidden=s_hidden)
     if flags.get("use_vision_mae_recon", False):
         _, _, m_mask, m_restore, m_mid = encode_image(image, P, spec, gumbel=noise.get("gumbel_mae"),
                                                       mask_noise=noise["mask_noise"], mask_ratio=0.75,

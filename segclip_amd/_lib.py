@@ -54,7 +54,7 @@ class AttnDesc(C.Structure):
                 ("o_sb", i64), ("o_st", i64),
                 ("dq_sb", i64), ("dq_st", i64), ("dk_sb", i64), ("dk_st", i64), ("dv_sb", i64), ("dv_st", i64),
                 ("do_sb", i64), ("do_st", i64),
-                ("scale", f32), ("causal", i32), ("dtype", i32), ("flags", i32), ("colsum_part", vp)]
+                ("scale", f32), ("causal", i32), ("dtype", i32), ("flags", i32), ("colsum_part", vp), ("klen", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/segclip_hip.h
@@ -78,6 +78,8 @@ SIGNATURES = {
     "segclip_add": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
     "segclip_scale": (C.c_int, [vp, vp, vp, i64, vp]),
     "segclip_reduce_sum": (C.c_int, [vp, vp, i64, f32, vp]),
+    "segclip_ce_labels_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, i64, i64, vp]),
+    "segclip_ce_labels_bwd": (C.c_int, [vp, vp, vp, i64, vp, vp, vp, i64, i64, vp]),
     "segclip_im2col": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_int, C.c_int, vp]),
     "segclip_im2col_ld": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_int, C.c_int, i64, vp]),
     "segclip_vis_assemble": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),

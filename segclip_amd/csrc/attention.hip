@@ -93,6 +93,7 @@ struct FwdArgs {
   int H, Tq, Tk, hd;
   int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
   float scale; int causal;
+  const int* klen;  // nullable: valid keys per sample
 };
 
 constexpr int KCHUNK = 256;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
   const bf16_t* Vp = a.V + (int64_t)b * a.v_sb + (int64_t)h * a.hd;
   const int qg = q0 + li;
   const bool wave_active = q0 < a.Tq;
+  const int kvalid = a.klen ? (a.klen[b] < a.Tk ? a.klen[b] : a.Tk) : a.Tk;
 
   bf16x8_t qf[4];
 #pragma unroll
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = c0 + kt + accrow(r, lh);
-        const bool ok = key < a.Tk && (!a.causal || key <= qg);
+        const bool ok = key < kvalid && (!a.causal || key <= qg);
         p[r] = ok ? s[r] * a.scale : -INFINITY;
         mx = fmaxf(mx, p[r]);
       }
@@ -195,6 +197,7 @@ struct BwdArgs {
   int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, do_sb, do_st;
   int64_t dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
   float scale; int causal;
+  const int* klen;     // nullable: valid keys per sample (fused kernel only)
   float* colsum_part;  // nullable: [B][3][H*hd] token sums of dQ | dK | dV (the in_proj bias gradient, per sample)
 };
 
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
   const bf16_t* Op = a.O + b * a.o_sb + hoff;
   const bf16_t* Gp = a.dO + b * a.do_sb + hoff;
   const int tqp = (a.Tq + 31) & ~31, tkp = (a.Tk + 31) & ~31;
+  const int kvalid = a.klen ? (a.klen[b] < a.Tk ? a.klen[b] : a.Tk) : a.Tk;
 
   stage_rows(Qt, Qp, a.q_st, 0, a.Tq, tqp, a.hd, tid, blockDim.x);
   // dO tile + D[q] = sum_d dO*O (8 consecutive lanes share a row); branch-free batched loads as in stage_rows
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = rg * 4 + j, q = qb + j;
-          const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
+          const bool ok = key < kvalid && q < a.Tq && (!a.causal || key <= q);
           const float pv = ok ? __expf(s[r] * a.scale - l4[j]) : 0.f;
           p[r] = pv;
           ds[r] = pv * (dp[r] - d4[j]) * a.scale;
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + accrow(r, lh);
-        const bool ok = key < a.Tk && q < a.Tq && (!a.causal || key <= q);
+        const bool ok = key < kvalid && q < a.Tq && (!a.causal || key <= q);
         const float pv = ok ? __expf(s[r] * a.scale - lq) : 0.f;
         ds[r] = pv * (dp[r] - dq_) * a.scale;
       }
@@ -462,13 +466,15 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 
 // ------------------------------- f32 path helpers -------------------------------------------
 // in-place row softmax of S (rows = B*H*Tq, Tk cols), causal mask by query index row % Tq
-__global__ void softmax_rows_kernel(float* __restrict__ S, int64_t rows, int Tq, int Tk, int causal) {
+__global__ void softmax_rows_kernel(float* __restrict__ S, int64_t rows, int Tq, int Tk, int causal, const int* klen,
+                                    int H) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int q = (int)(row % Tq);
   float* s = S + row * Tk;
-  const int lim = causal ? (q + 1 < Tk ? q + 1 : Tk) : Tk;
+  int lim = causal ? (q + 1 < Tk ? q + 1 : Tk) : Tk;
+  if (klen) { const int kv = klen[row / ((int64_t)H * Tq)]; lim = kv < lim ? kv : lim; }
   float mx = -INFINITY;
   for (int c = lane; c < lim; c += 64) mx = fmaxf(mx, s[c]);
   mx = wave_max(mx);
@@ -532,6 +538,8 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     a.H = (int)d->H; a.Tq = (int)d->Tq; a.Tk = (int)d->Tk; a.hd = (int)d->hd;
     a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st;
     a.o_sb = d->o_sb; a.o_st = d->o_st; a.scale = d->scale; a.causal = d->causal;
+    a.klen = (const int*)d->klen;
+    SEGCLIP_REQUIRE(!(d->klen && (d->flags & SEGCLIP_ATTN_FP8)), "attn_fwd: klen is not supported by the fp8 kernel");
     const int tiles = (int)cdiv(d->Tq, 32);
     const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
     SEGCLIP_REQUIRE(d->B * d->H <= 65535, "attn_fwd: B*H too large");
@@ -558,7 +566,7 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
   if (rc) return rc;
   const int64_t rows = d->B * d->H * d->Tq;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, P, rows, (int)d->Tq,
-                     (int)d->Tk, d->causal);
+                     (int)d->Tk, d->causal, (const int*)d->klen, (int)d->H);
   SEGCLIP_CHECK_LAUNCH("attn_softmax_rows");
   base_gemm(g, d);
   g.A = P; g.B = d->V; g.C = d->O; g.M = d->Tq; g.N = d->hd; g.K = d->Tk;
@@ -586,7 +594,9 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.dq_sb = d->dq_sb; a.dq_st = d->dq_st; a.dk_sb = d->dk_sb; a.dk_st = d->dk_st; a.dv_sb = d->dv_sb; a.dv_st = d->dv_st;
     a.scale = d->scale; a.causal = d->causal;
     a.colsum_part = (float*)d->colsum_part;
+    a.klen = (const int*)d->klen;
     if (d->Tq > TMAX || d->Tk > TMAX) {
+      SEGCLIP_REQUIRE(d->klen == nullptr, "attn_bwd bf16: klen needs sequences of at most %d tokens", TMAX);
       // long sequences: two streaming launches (dK,dV | dQ), 8 owned tiles per workgroup
       SEGCLIP_REQUIRE(d->ws != nullptr, "attn_bwd bf16: workspace required for sequences longer than %d", TMAX);
       const size_t lds = bwd_stream_lds_bytes();

@@ -114,18 +114,18 @@ __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
 }
 
 // NSPLIT > 0: the sub-tile's local columns 0-31 / 32-63 live at global columns nw + 0..31 / nw + NSPLIT + 0..31.
+template <typename CT, int MODE, int NSPLIT>
+__device__ __forceinline__ void epilogue_lds_plain(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
+                                                   int64_t nw, int lane, int64_t coff);
+
 template <typename CT, int MODE, int NSPLIT = 0>
 __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
                                              int lane, int64_t coff, int64_t roff) {
+  if (MODE != EPI_DACT && !g.residual) {   // nothing to load besides the bias: the rolled, low-register form
+    epilogue_lds_plain<CT, MODE, NSPLIT>(g, acc, t, mw, nw, lane, coff);
+    return;
+  }
   const int li = lane & 31, lk = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
-  __builtin_amdgcn_wave_barrier();
   constexpr int W = sizeof(CT) == 2 ? 8 : 4;      // columns per lane
   constexpr int LPR = 64 / W;                      // lanes per row
   constexpr int RPI = 64 / LPR;                    // rows per iteration
@@ -141,39 +141,49 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
       bias[c] = b[0]; bias[c + 1] = b[1]; bias[c + 2] = b[2]; bias[c + 3] = b[3];
     }
   }
-  // rows are processed in batches of 4 iterations: the residual / pre-activation loads of a batch are all
-  // issued before the first use (one exposed memory latency per batch instead of one per row)
+  // ALL residual / pre-activation loads of the 64x64 sub-tile are issued first (<= 64 VGPRs: the operand-fragment
+  // registers are free by now), so their memory latency is paid once and overlaps the accumulator -> LDS pass.  With
+  // batches of 4 rows (the first version) an fp32-residual epilogue paid 8 dependent round trips per tile: +26..57 us
+  // per launch on the out_proj / c_proj GEMMs.
+  constexpr int NIT = 64 / RPI;
+  constexpr int RW = W / 4;  // 16-byte words per lane for an fp32 side operand
+  f32x4 side_f[NIT][RW];   // fp32 residual
+  u32x4 side_h[NIT];       // bf16 residual (W==8) / bf16 aux
+  u32x2 side_q[NIT];       // bf16 residual when W==4
+  f32x4 aux_f[NIT];        // fp32 aux (W==4)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t m = mw + it * RPI + rl;
+    if (MODE == EPI_DACT) {
+      if (sizeof(CT) == 2) side_h[it] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.aux + coff + m * g.ldaux + n);
+      else aux_f[it] = *reinterpret_cast<const f32x4*>((const float*)g.aux + coff + m * g.ldaux + n);
+    } else if (g.residual) {
+      const int64_t o = roff + m * g.ldr + n;
+      if (g.r_dtype == SEGCLIP_BF16) {
+        if (W == 8) side_h[it] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.residual + o);
+        else side_q[it] = *reinterpret_cast<const u32x2*>((const bf16_t*)g.residual + o);
+      } else {
+#pragma unroll
+        for (int c = 0; c < RW; ++c) side_f[it][c] = *reinterpret_cast<const f32x4*>((const float*)g.residual + o + 4 * c);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();
   float csum[W];
 #pragma unroll
   for (int c = 0; c < W; ++c) csum[c] = 0.f;
-  constexpr int NIT = 64 / RPI, BATCH = 4;
-  constexpr int RW = W / 4;  // 16-byte words per lane for an fp32 side operand
-#pragma unroll 1
-  for (int it0 = 0; it0 < NIT; it0 += BATCH) {
-    f32x4 side_f[BATCH][RW];   // fp32 residual
-    u32x4 side_h[BATCH];       // bf16 residual (W==8) / bf16 aux
-    u32x2 side_q[BATCH];       // bf16 residual when W==4
-    f32x4 aux_f[BATCH];        // fp32 aux (W==4)
 #pragma unroll
-    for (int bi = 0; bi < BATCH; ++bi) {
-      const int64_t m = mw + (it0 + bi) * RPI + rl;
-      if (MODE == EPI_DACT) {
-        if (sizeof(CT) == 2) side_h[bi] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.aux + coff + m * g.ldaux + n);
-        else aux_f[bi] = *reinterpret_cast<const f32x4*>((const float*)g.aux + coff + m * g.ldaux + n);
-      } else if (g.residual) {
-        const int64_t o = roff + m * g.ldr + n;
-        if (g.r_dtype == SEGCLIP_BF16) {
-          if (W == 8) side_h[bi] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.residual + o);
-          else side_q[bi] = *reinterpret_cast<const u32x2*>((const bf16_t*)g.residual + o);
-        } else {
-#pragma unroll
-          for (int c = 0; c < RW; ++c) side_f[bi][c] = *reinterpret_cast<const f32x4*>((const float*)g.residual + o + 4 * c);
-        }
-      }
-    }
-#pragma unroll
-    for (int bi = 0; bi < BATCH; ++bi) {
-      const int row = (it0 + bi) * RPI + rl;
+  for (int it = 0; it < NIT; ++it) {
+    {
+      const int bi = it;
+      const int row = it * RPI + rl;
       const int64_t m = mw + row;
       float v[W];
 #pragma unroll
@@ -235,6 +245,93 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
     }
   }
   if (g.colsum_part) {  // column sums of this wave's 64 rows (bias gradient of the producing Linear)
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      float x = csum[c];
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+      if (rl == 0) g.colsum_part[(mw >> 6) * g.N + n + c] = x;
+    }
+  }
+}
+
+// epilogue_lds without residual / act' operands (bias, activation + pre-activation copy, column sums): rows are
+// processed by a rolled loop, 4 at a time (fully unrolling it, as the side-operand form above does, spilled registers
+// and cost the QuickGELU epilogue +25 %).
+template <typename CT, int MODE, int NSPLIT>
+__device__ __forceinline__ void epilogue_lds_plain(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
+                                                   int64_t nw, int lane, int64_t coff) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();
+  constexpr int W = sizeof(CT) == 2 ? 8 : 4;
+  constexpr int LPR = 64 / W;
+  constexpr int RPI = 64 / LPR;
+  const int cl = lane % LPR, rl = lane / LPR;
+  const int64_t n = NSPLIT > 0 ? nw + ((cl * W) >> 5) * NSPLIT + ((cl * W) & 31) : nw + cl * W;
+  float bias[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) bias[c] = 0.f;
+  if (g.bias) {
+#pragma unroll
+    for (int c = 0; c < W; c += 4) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n + c);
+      bias[c] = b[0]; bias[c + 1] = b[1]; bias[c + 2] = b[2]; bias[c + 3] = b[3];
+    }
+  }
+  float csum[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) csum[c] = 0.f;
+  constexpr int NIT = 64 / RPI, BATCH = 4;
+#pragma unroll 1
+  for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+#pragma unroll
+    for (int bi = 0; bi < BATCH; ++bi) {
+      const int row = (it0 + bi) * RPI + rl;
+      const int64_t m = mw + row;
+      float v[W];
+#pragma unroll
+      for (int c = 0; c < W; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
+        v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
+      }
+#pragma unroll
+      for (int c = 0; c < W; ++c) v[c] += bias[c];
+      if (MODE == EPI_ACT) {
+        if (g.aux) {
+          if (sizeof(CT) == 2) {
+            u32x4 p;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+            __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n));
+          } else {
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
+                                        reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] = apply_act(g.act, v[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < W; ++c) csum[c] += v[c];
+      if (sizeof(CT) == 2) {
+        u32x4 p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+        __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n));
+      } else {
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
+                                    reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n));
+      }
+    }
+  }
+  if (g.colsum_part) {
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       float x = csum[c];

@@ -343,6 +343,43 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const float* __r
   }
 }
 
+// cross entropy with explicit labels and an ignore index; one wave per row (the vocabulary: 49408 columns)
+__global__ void ce_labels_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int64_t ignore,
+                                     float* __restrict__ lse, float* __restrict__ loss_rows, float* __restrict__ valid,
+                                     int64_t rows, int64_t cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = logits + row * cols;
+  float mx = -INFINITY;
+  for (int64_t c = lane; c < cols; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int64_t c = lane; c < cols; c += 64) s += expf(p[c] - mx);
+  s = wave_sum(s);
+  const float l = mx + logf(s);
+  if (lane == 0) {
+    const int64_t lab = labels[row];
+    const bool ok = lab != ignore && lab >= 0 && lab < cols;
+    lse[row] = l;
+    loss_rows[row] = ok ? l - p[lab] : 0.f;
+    valid[row] = ok ? 1.f : 0.f;
+  }
+}
+__global__ void ce_labels_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                     const int64_t* __restrict__ labels, int64_t ignore, const float* __restrict__ gscale,
+                                     const float* __restrict__ inv_count, float* __restrict__ dlogits, int64_t rows,
+                                     int64_t cols) {
+  const float gs = gscale[0] * inv_count[0];
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cols, c = i % cols;
+    const int64_t lab = labels[row];
+    const bool ok = lab != ignore && lab >= 0 && lab < cols;
+    dlogits[i] = ok ? gs * (expf(logits[i] - lse[row]) - (c == lab ? 1.f : 0.f)) : 0.f;
+  }
+}
+
 // superpixel-KL: one block per image.  hard (B,G,T) one-hot, seg (B,T) int64.  Emits loss_rows[b] (already
 // divided by coef = B*T*G and by 2) and the un-scaled gradient dhard (B,G,T) of that per-image loss.
 constexpr int KL_MAXG = 16;
@@ -631,6 +668,23 @@ extern "C" int segclip_ce_bwd(const float* logits, const float* lse, const float
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid1d(rows * cols)), dim3(TPB), 0, ST, logits, lse, gscale_ptr, gscale, dlogits,
                      rows, cols, label_offset);
   SEGCLIP_CHECK_LAUNCH("ce_bwd");
+  return 0;
+}
+extern "C" int segclip_ce_labels_fwd(const float* logits, const int64_t* labels, int64_t ignore_index, float* lse,
+                                     float* loss_rows, float* valid, int64_t rows, int64_t cols, void* stream) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(ce_labels_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, ST, logits, labels, ignore_index, lse,
+                     loss_rows, valid, rows, cols);
+  SEGCLIP_CHECK_LAUNCH("ce_labels_fwd");
+  return 0;
+}
+extern "C" int segclip_ce_labels_bwd(const float* logits, const float* lse, const int64_t* labels, int64_t ignore_index,
+                                     const float* gscale, const float* inv_count, float* dlogits, int64_t rows,
+                                     int64_t cols, void* stream) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(ce_labels_bwd_kernel, dim3(grid1d(rows * cols)), dim3(TPB), 0, ST, logits, lse, labels, ignore_index,
+                     gscale, inv_count, dlogits, rows, cols);
+  SEGCLIP_CHECK_LAUNCH("ce_labels_bwd");
   return 0;
 }
 extern "C" int segclip_superpixel_kl(const float* hard, const int64_t* seg, float* loss_rows, float* dhard, int64_t B,

@@ -102,9 +102,13 @@ class SegCLIP(SegCLIPPreTrainedModel):
             self.vis_mae_decoder = MAEDecoder(vision_width, vision_width // 2, image_resolution, vision_patch_size,
                                               decoder_depth=3, decoder_num_heads=8, mlp_ratio=4.,
                                               norm_layer=partial(nn.LayerNorm, eps=1e-6))
+        mae_seq_mask_ratio = get_attr(task_config, "mae_seq_mask_ratio", default_value=0.15)
         self.use_text_mae_recon = get_attr(task_config, "use_text_mae_recon", default_value=False)
-        if self.use_text_mae_recon:
-            raise NotImplementedError("text-MAE reconstruction is outside the hot path (SURVEY.md section 2.1)")
+        if self.use_text_mae_recon:   # modules/modeling.py:156-166
+            self.seq_mask_ratio = mae_seq_mask_ratio
+            self.seq_mae_decoder = MAEDecoder(embed_dim, embed_dim // 2, image_resolution, vision_patch_size,
+                                              decoder_depth=3, decoder_num_heads=8, mlp_ratio=4., choice_seq=True,
+                                              pred_len=vocab_size, seq_len=self.task_config.max_words)
         self.use_seglabel = get_attr(task_config, "use_seglabel", default_value=False)
         self.apply(self.init_weights)
         # per-model overrides of the run-time switches (segclip_amd/config.py), e.g. {"compute_dtype": torch.bfloat16}
@@ -171,6 +175,18 @@ class SegCLIP(SegCLIPPreTrainedModel):
             clutering_loss = ops.SuperpixelKLFn.apply(hard, image_seg_)
             loss = loss + clutering_loss
             self.last_losses["kl"] = clutering_loss.detach()
+        if self.use_text_mae_recon:   # modules/modeling.py:226-236
+            attention_mask = attention_mask.view(-1, attention_mask.shape[-1])
+            _, seq_hidden, seq_mae_mask, seq_mae_ids_restore = self.get_sequence_output(
+                input_ids, token_type_ids, attention_mask, shaped=True, return_hidden=True, mask_ratio=self.seq_mask_ratio)
+            seq_mae_mask = seq_mae_mask.view(-1, seq_mae_mask.size(-1))
+            seq_mae_ids_restore = seq_mae_ids_restore.view(-1, seq_mae_ids_restore.size(-1))
+            _mae_mask = (seq_mae_mask + attention_mask).gt(1)
+            self.last_text_mae = (seq_mae_mask, seq_mae_ids_restore, seq_hidden)
+            seq_mae_loss = self.seq_mae_decoder.forward_seq(input_ids, seq_hidden, _mae_mask, seq_mae_ids_restore,
+                                                            attention_mask)
+            loss = loss + seq_mae_loss
+            self.last_losses["text_mae"] = seq_mae_loss.detach()
         if self.use_vision_mae_recon:
             _, vis_hidden, vis_mae_mask, vis_mae_ids_restore, mid_mae_states = self.get_visual_output(
                 image, shaped=True, image_frame=image_frame, return_hidden=True, mask_ratio=self.vis_mask_ratio)
@@ -195,6 +211,9 @@ class SegCLIP(SegCLIPPreTrainedModel):
         bs_pair = input_ids.size(0)
         sequence_hidden = seq_model.encode_text(input_ids, return_hidden=return_hidden, mask_ratio=mask_ratio)
         if isinstance(sequence_hidden, tuple):
+            if mask_ratio > 0:
+                return tuple([itm.float().view(bs_pair, -1, itm.size(-1)) for itm in sequence_hidden[:2]]
+                             + [itm.view(bs_pair, -1, itm.size(-1)) for itm in sequence_hidden[2:]])
             return tuple(itm.float().view(bs_pair, -1, itm.size(-1)) for itm in sequence_hidden)
         return sequence_hidden.float().view(bs_pair, -1, sequence_hidden.size(-1))
 

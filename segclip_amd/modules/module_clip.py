@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import config, ops
-from .module_clip_util import CLIP_Module, LayerNorm, _MODELS
+from .module_clip_util import CLIP_Module, LayerNorm, _MODELS, random_masking
 from .module_clip_ttransformer import TextTransformer
 from .module_clip_vtransformer import VisualTransformer
 
@@ -62,11 +62,22 @@ class CLIP(CLIP_Module):
         return self.transformer.forward_nld(x, causal=True)
 
     def encode_text(self, text, attn_mask=None, return_hidden=False, mask_ratio=0.):
-        """modules/module_clip.py:105-143 (mask_ratio > 0 is the text-MAE branch: out of scope)."""
-        if mask_ratio > 0.:
-            raise NotImplementedError("text-MAE branch is out of scope (SURVEY.md section 2.1)")
+        """modules/module_clip.py:105-143.  mask_ratio > 0 (text-MAE): the kept tokens run through the causal tower in
+        the SHUFFLED order random_masking leaves them in, exactly as the reference does."""
         if attn_mask is not None and not callable(attn_mask):
-            raise NotImplementedError("padding masks are only reachable from the text-MAE branch (out of scope)")
+            raise NotImplementedError("encode_text: only the causal (callable) attention mask is used by the model")
+        if mask_ratio > 0.:
+            assert return_hidden is True
+            x = ops.EmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
+            x, mae_mask, mae_ids_restore, ids_keep = random_masking(x, mask_ratio, keep_cls=True, keep_sep=True,
+                                                                    sep_pos=text.argmax(dim=-1))
+            text = torch.gather(text, dim=1, index=ids_keep)
+            x = self.transformer.forward_nld(x, causal=True)
+            hidden_ln = self.ln_final(x)
+            hidden = ops.linear(hidden_ln, self.text_projection, None, out_dtype=torch.float32,
+                                act_dtype=config.compute_dtype, w_kn=True)
+            pooled = ops.GatherRowsFn.apply(hidden, text.argmax(dim=-1).view(-1, 1)).squeeze(1)
+            return pooled, hidden, mae_mask, mae_ids_restore
         x = self._text_trunk(text)
         eot = text.argmax(dim=-1)
         if not return_hidden:

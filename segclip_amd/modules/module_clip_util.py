@@ -27,14 +27,26 @@ class QuickGELU(nn.Module):
 
 
 def random_masking(x, mask_ratio, keep_cls=False, keep_sep=False, cls_pos=None, sep_pos=None):
-    """modules/module_clip_util.py:91-124 for keep_cls=True (the vision-MAE use): x (N, L, D) with the
-    CLS row at index 0.  Returns x_masked, mask, ids_restore, ids_keep."""
-    if not keep_cls or keep_sep or cls_pos is not None:
-        raise NotImplementedError("random_masking: only the keep_cls=True vision path is on the hot path")
+    """modules/module_clip_util.py:91-124: x (N, L, D) -> x_masked, mask, ids_restore, ids_keep.
+    keep_cls pins position 0; keep_sep (text-MAE) is reproduced AS WRITTEN in the reference:
+    `noise.scatter_(dim=1, index=sep_pos.unsqueeze(0), value=-1)` with a (1, N) index pins the separator positions
+    of every sample in ROW 0 only.  The sort is segclip_mask_sort (stable rank sort = torch's CPU argsort, ties keep
+    index order)."""
+    if cls_pos is not None:
+        raise NotImplementedError("random_masking: cls_pos is never used by the model")
     N, Lq, D = x.shape
     len_keep = int(Lq * (1 - mask_ratio))
     noise = config.rand((N, Lq), x.device)
-    ids_shuffle, ids_restore, mask = ops.mask_sort(noise, len_keep)
+    if keep_cls or keep_sep:
+        noise = noise.clone()
+    if keep_cls:
+        noise[:, 0] = -1.
+    if keep_sep:
+        assert sep_pos is not None
+        noise[0].index_fill_(0, sep_pos.reshape(-1), -1.)
+    if not keep_cls:
+        raise NotImplementedError("random_masking: the model only calls it with keep_cls=True")
+    ids_shuffle, ids_restore, mask = ops.mask_sort(noise, len_keep)   # the kernel pins position 0 itself as well
     ids_keep = ids_shuffle[:, :len_keep].contiguous()
     x_masked = ops.GatherRowsFn.apply(x, ids_keep)
     return x_masked, mask, ids_restore, ids_keep

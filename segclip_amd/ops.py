@@ -231,9 +231,15 @@ def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, wa
     return tuple(out)
 
 
-def _attn_desc(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, scale, causal, q_off=0, k_off=0, v_off=0, fp8=False):
+def _attn_desc(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, scale, causal, q_off=0, k_off=0, v_off=0, fp8=False,
+               klen=None):
     d = L.AttnDesc()
-    d.flags = L.ATTN_FP8 if fp8 else 0
+    d.flags = L.ATTN_FP8 if (fp8 and klen is None) else 0
+    if klen is not None:
+        if klen.dtype != torch.int32 or klen.numel() != B or not klen.is_contiguous():
+            raise TypeError("attention: klen must be a contiguous int32 tensor of B entries")
+        L.require_cuda(klen)
+        d.klen = L.ptr(klen)
     d.Q, d.K, d.V, d.O = _off(q, q_off), _off(k, k_off), _off(v, v_off), L.ptr(o)
     d.B, d.H, d.Tq, d.Tk, d.hd = B, H, Tq, Tk, hd
     d.q_sb, d.q_st = qs
@@ -496,7 +502,7 @@ class ResBlockFn(Function):
 
     @staticmethod
     def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr, n_head, causal, act, eps,
-                act_dtype):
+                act_dtype, klen=None):
         B, T, D = x.shape
         M = B * T
         x2 = x.contiguous().view(M, D)
@@ -508,7 +514,7 @@ class ResBlockFn(Function):
         from . import config as _cfg
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, (T * 3 * D, 3 * D), (T * 3 * D, 3 * D),
                         (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D,
-                        fp8=bool(_cfg.attn_fp8) and act_dtype == torch.bfloat16)
+                        fp8=bool(_cfg.attn_fp8) and act_dtype == torch.bfloat16, klen=klen)
         stats = p_attn_fwd(ad, x)
         x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
         y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
@@ -517,6 +523,7 @@ class ResBlockFn(Function):
         ctx.save_for_backward(x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2,
                               wfc_c, u, h, wpr_c)
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
+        ctx.klen = klen
         ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
         return xo.view(B, T, D)
 
@@ -573,7 +580,7 @@ class ResBlockFn(Function):
         dqkv = _empty((M, 3 * D), act_dtype, g)
         s3 = (T * 3 * D, 3 * D)
         ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
-                        0, D, 2 * D)
+                        0, D, 2 * D, klen=ctx.klen)
         part = _empty((B, 3 * D), torch.float32, g) if (bf and need[4]) else None  # in_proj bias gradient per sample
         p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
         dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
@@ -588,7 +595,7 @@ class ResBlockFn(Function):
         if bf:
             dx._segclip_bf16 = r[3].view(B, T, D)
         return (dx, dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class CrossAttnFn(Function):
@@ -821,6 +828,46 @@ class CrossEntropyFn(Function):
         L.check(L.load().segclip_ce_bwd(L.ptr(logits), L.ptr(lse), L.ptr(g), 1.0, L.ptr(dl), rows, cols,
                                         ctx.label_offset, L.stream()), "ce_bwd")
         return dl, None
+
+
+class CrossEntropyLabelsFn(Function):
+    """nn.CrossEntropyLoss(ignore_index) with explicit labels: mean over the rows whose label is not ignored
+    (text-MAE vocabulary loss, modules/module_mae.py:351-353).  logits (R, V) fp32, labels (R,) int64."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        logits = logits.contiguous()
+        labels = labels.to(torch.int64).contiguous()
+        L.require_cuda(logits, labels)
+        rows, cols = logits.shape
+        lib = L.load()
+        lse, lr, valid = (_empty((rows,), torch.float32, logits) for _ in range(3))
+        L.check(lib.segclip_ce_labels_fwd(L.ptr(logits), L.ptr(labels), int(ignore_index), L.ptr(lse), L.ptr(lr), L.ptr(valid),
+                                          rows, cols, L.stream()), "ce_labels_fwd")
+        tot, cnt, loss = (_empty((), torch.float32, logits) for _ in range(3))
+        L.check(lib.segclip_reduce_sum(L.ptr(lr), L.ptr(tot), rows, 1.0, L.stream()), "reduce_sum")
+        L.check(lib.segclip_reduce_sum(L.ptr(valid), L.ptr(cnt), rows, 1.0, L.stream()), "reduce_sum")
+        inv = torch.reciprocal(cnt)
+        L.check(lib.segclip_scale(L.ptr(tot), L.ptr(inv), L.ptr(loss), 1, L.stream()), "scale")
+        ctx.save_for_backward(logits, lse, labels, inv)
+        ctx.ignore_index = int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse, labels, inv = ctx.saved_tensors
+        rows, cols = logits.shape
+        g = g.contiguous().float()
+        dl = torch.empty_like(logits)
+        L.check(L.load().segclip_ce_labels_bwd(L.ptr(logits), L.ptr(lse), L.ptr(labels), ctx.ignore_index, L.ptr(g),
+                                               L.ptr(inv), L.ptr(dl), rows, cols, L.stream()), "ce_labels_bwd")
+        return dl, None, None
+
+
+def prefix_mask_lengths(attention_mask):
+    """(B, L) 0/1 attention mask of END-PADDED captions (the dataloader contract, dataloaders/dataloader_cc_retrieval.py:
+    valid tokens first) -> int32 (B,) number of valid keys, the form the attention kernels take the key-padding mask in."""
+    return attention_mask.reshape(attention_mask.shape[0], -1).to(torch.int32).sum(dim=1, dtype=torch.int32).contiguous()
 
 
 class SuperpixelKLFn(Function):

@@ -116,6 +116,8 @@ def synthetic_noise(spec, batch, seed=0, device="cpu", groups=8):
     out = dict(gumbel_main=gumbel((batch, groups, n)),
                mask_noise=torch.rand(batch, n + 1, generator=g, dtype=torch.float32),
                gumbel_mae=gumbel((batch, groups, keep - 1)))
+    # text-MAE masking noise (drawn last so that the three tensors above keep their round-1 values)
+    out["text_mask_noise"] = torch.rand(batch, spec["context_length"], generator=g, dtype=torch.float32)
     return {k: v.to(device) for k, v in out.items()}
 
 
@@ -172,7 +174,8 @@ def build_model(spec, flags=None, rank=0, world_size=1, device="cuda", closed_fo
     flags = flags or {}
     args = argparse.Namespace(local_rank=0, rank=rank, world_size=world_size, pretrained_clip_name="ViT-B/16",
                               first_stage_layer=10, use_vision_mae_recon=flags.get("use_vision_mae_recon", False),
-                              use_text_mae_recon=False, use_seglabel=flags.get("use_seglabel", False),
+                              use_text_mae_recon=flags.get("use_text_mae_recon", False),
+                              use_seglabel=flags.get("use_seglabel", False),
                               mae_vis_mask_ratio=0.75, max_words=spec["context_length"])
     import logging
     lg = logging.getLogger("seg")

@@ -20,8 +20,11 @@ def oracle_params(spec, names_shapes, requires_grad=True):
     P = {}
     for name, shape in names_shapes:
         if name.endswith("decoder_pos_embed"):
-            n = (spec["image_res"] // spec["patch"])
-            t = so.sincos_pos_embed_2d(shape[-1], n).reshape(shape)
+            if name.startswith("seq_mae_decoder."):
+                t = so.position_encoding_init(shape[-2], shape[-1]).reshape(shape)
+            else:
+                n = (spec["image_res"] // spec["patch"])
+                t = so.sincos_pos_embed_2d(shape[-1], n).reshape(shape)
             P[name] = t
             continue
         t = synth.closed_form_tensor(name, shape).float()
