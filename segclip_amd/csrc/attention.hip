@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
   const int qg = q0 + li;
   const bool wave_active = q0 < a.Tq;
   const int kvalid = a.klen ? (a.klen[b] < a.Tk ? a.klen[b] : a.Tk) : a.Tk;
+  const float sc2 = a.scale * 1.4426950408889634f;  // scale * log2(e): the running max m is kept in the log2 domain
 
   bf16x8_t qf[4];
 #pragma unroll
@@ -143,22 +144,30 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kt, kc, lane), qf[kc], s, 0, 0, 0);
+      // softmax in the log2 domain (one fma + v_exp_f32 per element); the key / causal masks are only evaluated on
+      // tiles that contain masked elements (wave-uniform test)
+      const bool edge = c0 + kt + 32 > kvalid || (a.causal && c0 + kt + 31 > q0);
       float p[16];
       float mx = -INFINITY;
+      if (edge) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = c0 + kt + accrow(r, lh);
-        const bool ok = key < kvalid && (!a.causal || key <= qg);
-        p[r] = ok ? s[r] * a.scale : -INFINITY;
-        mx = fmaxf(mx, p[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = c0 + kt + accrow(r, lh);
+          const bool ok = key < kvalid && (!a.causal || key <= qg);
+          p[r] = ok ? s[r] * sc2 : -INFINITY;
+          mx = fmaxf(mx, p[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = s[r] * sc2; mx = fmaxf(mx, p[r]); }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
       const float msafe = mn == -INFINITY ? 0.f : mn;
-      const float alpha = __expf(m - msafe);  // m = -inf -> 0
+      const float alpha = __builtin_amdgcn_exp2f(m - msafe);  // m = -inf -> 0
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __expf(p[r] - msafe); rs += p[r]; }
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - msafe); rs += p[r]; }
       rs += __shfl_xor(rs, 32, 64);
       l = l * alpha + rs;
       m = mn;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
         *reinterpret_cast<u32x2*>(Op + d) = t;
       }
     }
-  if (lh == 0) a.lse[((int64_t)b * a.H + h) * a.Tq + qg] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+  if (lh == 0) a.lse[((int64_t)b * a.H + h) * a.Tq + qg] = (l > 0.f) ? m * 0.6931471805599453f + __logf(l) : -INFINITY;
 }
 
 struct BwdArgs {
@@ -297,13 +306,14 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
           *reinterpret_cast<u32x4*>(Gt + swz(r, c * 8)) = g;
           if (c == 0) {
             Ds[r] = sdot;
-            Ls[r] = r < a.Tq ? a.lse[((int64_t)b * a.H + h) * a.Tq + r] : 0.f;
+            Ls[r] = r < a.Tq ? a.lse[((int64_t)b * a.H + h) * a.Tq + r] * 1.4426950408889634f : 0.f;  // log2 domain
           }
         }
       }
     }
   }
   __syncthreads();
+  const float sc2 = a.scale * 1.4426950408889634f;
 
   // ---------------- pass A: this wave owns key tiles; dK, dV ----------------
   for (int k0 = wave * 32; k0 < tkp; k0 += nw * 32) {
@@ -328,6 +338,9 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, q0, kc, lane), kf[kc], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gt, q0, kc, lane), vf[kc], dp, 0, 0, 0);
       }
+      // P = exp2(S * scale*log2e - lse*log2e): one fma + v_exp_f32; dS is kept WITHOUT the softmax scale (applied once
+      // to dK, the column sums and dQ at the end); masks only on tiles that contain masked elements (wave-uniform)
+      const bool edge = k0 + 32 > kvalid || q0 + 32 > a.Tq || (a.causal && k0 + 31 > q0);
       float p[16], ds[16];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
@@ -337,10 +350,10 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = rg * 4 + j, q = qb + j;
-          const bool ok = key < kvalid && q < a.Tq && (!a.causal || key <= q);
-          const float pv = ok ? __expf(s[r] * a.scale - l4[j]) : 0.f;
+          float pv = __builtin_amdgcn_exp2f(s[r] * sc2 - l4[j]);
+          if (edge) pv = (key < kvalid && q < a.Tq && (!a.causal || key <= q)) ? pv : 0.f;
           p[r] = pv;
-          ds[r] = pv * (dp[r] - d4[j]) * a.scale;
+          ds[r] = pv * (dp[r] - d4[j]);
           csl += ds[r];
         }
       }
@@ -353,10 +366,12 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
         dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, q0 + 16, dt * 32, lane), sb1, dk[dt], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] *= a.scale; dk[1][r] *= a.scale; }
     store_acc_T(a.dK + b * a.dk_sb + hoff, a.dk_st, key, a.Tk, a.hd, dk, lh);
     store_acc_T(a.dV + b * a.dv_sb + hoff, a.dv_st, key, a.Tk, a.hd, dv, lh);
     csl += __shfl_xor(csl, 32, 64);
-    if (lh == 0) Cs[key] = csl;
+    if (lh == 0) Cs[key] = csl * a.scale;
   }
 
   // token sums of dV (= token sums of dO: the rows of P sum to one) while dO is still in LDS
@@ -402,13 +417,16 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, k0, kc, lane), qf[kc], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vt, k0, kc, lane), gf[kc], dp, 0, 0, 0);
       }
+      const bool edge = k0 + 32 > kvalid || q0 + 32 > a.Tq || (a.causal && k0 + 31 > q0);
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = k0 + accrow(r, lh);
-        const bool ok = key < kvalid && q < a.Tq && (!a.causal || key <= q);
-        const float pv = ok ? __expf(s[r] * a.scale - lq) : 0.f;
-        ds[r] = pv * (dp[r] - dq_) * a.scale;
+        float pv = __builtin_amdgcn_exp2f(s[r] * sc2 - lq);
+        if (edge) {
+          const int key = k0 + accrow(r, lh);
+          pv = (key < kvalid && q < a.Tq && (!a.causal || key <= q)) ? pv : 0.f;
+        }
+        ds[r] = pv * (dp[r] - dq_);
       }
       const bf16x8_t sb0 = pack8(ds), sb1 = pack8(ds + 8);
 #pragma unroll
@@ -417,6 +435,8 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
         dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, k0 + 16, dt * 32, lane), sb1, dq[dt], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] *= a.scale; dq[1][r] *= a.scale; }
     store_acc_T(a.dQ + b * a.dq_sb + hoff, a.dq_st, q, a.Tq, a.hd, dq, lh);
   }
 
