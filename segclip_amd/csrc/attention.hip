@@ -342,19 +342,36 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
       // to dK, the column sums and dQ at the end); masks only on tiles that contain masked elements (wave-uniform)
       const bool edge = k0 + 32 > kvalid || q0 + 32 > a.Tq || (a.causal && k0 + 31 > q0);
       float p[16], ds[16];
+      if (edge) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int qb = q0 + 8 * rg + 4 * lh;  // 4 consecutive query rows per register group
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb);
+        for (int rg = 0; rg < 4; ++rg) {
+          const int qb = q0 + 8 * rg + 4 * lh;  // 4 consecutive query rows per register group
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = rg * 4 + j, q = qb + j;
-          float pv = __builtin_amdgcn_exp2f(s[r] * sc2 - l4[j]);
-          if (edge) pv = (key < kvalid && q < a.Tq && (!a.causal || key <= q)) ? pv : 0.f;
-          p[r] = pv;
-          ds[r] = pv * (dp[r] - d4[j]);
-          csl += ds[r];
+          for (int j = 0; j < 4; ++j) {
+            const int r = rg * 4 + j, q = qb + j;
+            const bool ok = key < kvalid && q < a.Tq && (!a.causal || key <= q);
+            const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * sc2 - l4[j]) : 0.f;
+            p[r] = pv;
+            ds[r] = pv * (dp[r] - d4[j]);
+            csl += ds[r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int qb = q0 + 8 * rg + 4 * lh;
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = rg * 4 + j;
+            const float pv = __builtin_amdgcn_exp2f(s[r] * sc2 - l4[j]);
+            p[r] = pv;
+            ds[r] = pv * (dp[r] - d4[j]);
+            csl += ds[r];
+          }
         }
       }
       const bf16x8_t pb0 = pack8(p), pb1 = pack8(p + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
@@ -419,14 +436,16 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
       }
       const bool edge = k0 + 32 > kvalid || q0 + 32 > a.Tq || (a.causal && k0 + 31 > q0);
       float ds[16];
+      if (edge) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pv = __builtin_amdgcn_exp2f(s[r] * sc2 - lq);
-        if (edge) {
+        for (int r = 0; r < 16; ++r) {
           const int key = k0 + accrow(r, lh);
-          pv = (key < kvalid && q < a.Tq && (!a.causal || key <= q)) ? pv : 0.f;
+          const bool ok = key < kvalid && q < a.Tq && (!a.causal || key <= q);
+          ds[r] = ok ? __builtin_amdgcn_exp2f(s[r] * sc2 - lq) * (dp[r] - dq_) : 0.f;
         }
-        ds[r] = pv * (dp[r] - dq_);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r] * sc2 - lq) * (dp[r] - dq_);
       }
       const bf16x8_t sb0 = pack8(ds), sb1 = pack8(ds + 8);
 #pragma unroll

@@ -126,9 +126,14 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  // Workgroups go to the XCDs round-robin in dispatch order (x fastest, then y): the (tile, K-split) space is walked
+  // split-major and cut into 8 contiguous chunks, one per XCD, so that the tiles that share an A row slab / B column
+  // slab - and, with split-K, the SAME K range - sit behind one L2.
+  const int nt = gridDim.x;
+  const int nwg = nt * gridDim.y, bid = blockIdx.x + nt * blockIdx.y;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int unit_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int wg = unit_id % nt, ksplit = unit_id / nt;
   const int64_t n0 = (int64_t)(wg % g.nbx) * BT, m0 = (int64_t)(wg / g.nbx) * BT;
   const int64_t z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.bsA1 + z2 * g.bsA2;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   const int64_t coff = z1 * g.bsC1 + z2 * g.bsC2;
   const int64_t roff = z1 * g.bsR1 + z2 * g.bsR2;
 
-  const int64_t kbeg = (int64_t)blockIdx.y * g.kper;
+  const int64_t kbeg = (int64_t)ksplit * g.kper;
   const int64_t kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
   const int nk = (int)((kend - kbeg) / BK);
 
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   const int64_t nw = n0 + wc * 32;  // this wave's first column (second strip at +128)
   if (g.splits > 1) {
     const int li = lane & 31, lk = lane >> 5;
-    float* slab = g.slab + ((int64_t)blockIdx.y * gridDim.z + z) * g.M * g.N;
+    float* slab = g.slab + ((int64_t)ksplit * gridDim.z + z) * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -35,11 +35,12 @@ _NO_EXCHANGE = bool(int(os.environ.get("SEGCLIP_GRADSYNC_NOEXCHANGE", "0")))  # 
 
 class _Slot:
     """A parameter's place in a flat gradient bucket."""
-    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner", "taken_pass")
+    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner", "taken_pass", "ptr")
 
     def __init__(self, bucket, offset, p, owner):
         self.bucket, self.offset, self.numel, self.shape = bucket, offset, p.numel(), tuple(p.shape)
         self.taken_pass = -1
+        self.ptr = owner._flat[bucket].data_ptr() + 4 * offset   # address of the slot (hook fast path: no view objects)
         self.param = weakref.ref(p)
         self.owner = weakref.ref(owner)
 
@@ -127,11 +128,11 @@ class GradSync(nn.Module):
             self._late.append(p)
             return
         g = p.grad
-        v = slot.view()
         if g.is_cuda:
             # the text tower's backward runs on its own stream: a bucket may hold gradients of several streams
-            self._bstreams[slot.bucket].add(torch.cuda.current_stream(g.device))
-        if g.data_ptr() != v.data_ptr():
+            self._bstreams[slot.bucket].add(torch.cuda.current_stream())
+        if g.data_ptr() != slot.ptr:
+            v = slot.view()
             v.copy_(g)
             p.grad = v
             self.stats["copies"] += 1

@@ -131,7 +131,7 @@ def fused_colsum_ok(M, N, K, dtype):
     return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0
 
 
-def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False):
+def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None):
     """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)
     want_colsum: also return the column sums of dx (= bias gradient of the Linear that produced the
     pre-activation), fused into the GEMM epilogue when the shape allows, else by the colsum kernel."""
@@ -143,10 +143,10 @@ def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=Fa
         raise TypeError("dgrad: aux dtype must equal output dtype")
     cs = None
     if want_colsum and fused_colsum_ok(M, K, N, out_dtype) and dy.dtype == torch.bfloat16:
-        cs = _empty((K,), torch.float32, dy)
+        cs = colsum_out if colsum_out is not None else _empty((K,), torch.float32, dy)
     p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None, colsum=cs)
     if want_colsum:
-        return dx, (cs if cs is not None else p_colsum(dx))
+        return dx, (cs if cs is not None else p_colsum(dx, out=colsum_out))
     return dx
 
 
@@ -184,10 +184,11 @@ def p_wgrad(dy, x, w_kn=False, out=None):
     return dw
 
 
-def p_colsum(x):
+def p_colsum(x, out=None):
     M, N = x.shape
     lib = L.load()
-    out = _empty((N,), torch.float32, x)
+    if out is None:
+        out = _empty((N,), torch.float32, x)
     ws = torch.empty(max(lib.segclip_colsum_ws_bytes(M, N), 4), dtype=torch.uint8, device=x.device)
     L.check(lib.segclip_colsum(L.ptr(x), L.ptr(out), L.ptr(ws), M, N, _ld(x), L.dt(x), L.stream()), "colsum")
     return out
@@ -204,17 +205,19 @@ def p_ln_fwd(x, w, b, eps, out_dtype):
     return y, mean, rstd
 
 
-def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, want_dres_colsum=False):
-    """-> dx, dgamma, dbeta [, dx_bf16] [, colsum(dres)]"""
+def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, want_dres_colsum=False, outs=(None, None, None)):
+    """-> dx, dgamma, dbeta [, dx_bf16] [, colsum(dres)];  outs = preallocated (dgamma, dbeta, colsum) buffers or None"""
     lib = L.load()
     dy = dy.contiguous()
     rows, cols = x.shape
     dx_dtype = dx_dtype or x.dtype
     dx = _empty((rows, cols), dx_dtype, x)
-    dw = _empty((cols,), torch.float32, x)
-    db = _empty((cols,), torch.float32, x)
+    dw = outs[0] if outs[0] is not None else _empty((cols,), torch.float32, x)
+    db = outs[1] if outs[1] is not None else _empty((cols,), torch.float32, x)
     dx16 = _empty((rows, cols), torch.bfloat16, x) if want_bf16 else None
-    dsum = _empty((cols,), torch.float32, x) if (want_dres_colsum and dres is not None) else None
+    dsum = None
+    if want_dres_colsum and dres is not None:
+        dsum = outs[2] if outs[2] is not None else _empty((cols,), torch.float32, x)
     if dres is not None:
         dres = dres.contiguous()
         if dres.dtype != dx_dtype:
@@ -525,6 +528,7 @@ class ResBlockFn(Function):
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
         ctx.klen = klen
         ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
+        ctx.vslots = tuple(_slot_of(w) for w in (ln1w, ln1b, bqkv, bo, ln2w, ln2b, bfc, bpr))
         return xo.view(B, T, D)
 
     @staticmethod
@@ -554,6 +558,7 @@ class ResBlockFn(Function):
         side = _wgrad_stream() if _cfg.overlap_wgrad else None
         sq, so, sf, sp = ctx.gslots  # weight gradients land directly in their all-reduce bucket (segclip_amd/dist.py)
         F4 = wfc_c.shape[0]
+        s_ln1w, s_ln1b, s_bqkv, s_bo, s_ln2w, s_ln2b, s_bfc, s_bpr = ctx.vslots   # ... and so do the 8 vector gradients
 
         def on_side(fn, *deps):
             if side is None:
@@ -566,11 +571,14 @@ class ResBlockFn(Function):
             return out
 
         # ---- MLP
-        du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True)  # (dy c_proj)*act'(u), colsum
+        du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
+                           colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None)  # (dy c_proj)*act'(u), colsum
         dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)))) if need[11] else None
         dy2 = p_dgrad(du, wfc_c, act_dtype)
         dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)))) if need[9] else None
-        r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
+        r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True,
+                     outs=(_slot_out(s_ln2w, (D,)) if need[7] else None, _slot_out(s_ln2b, (D,)) if need[8] else None,
+                           _slot_out(s_bpr, (D,)) if need[12] else None))
         dx1, dln2w, dln2b = r[0], r[1], r[2]
         dx1_16 = r[3] if bf else dx1
         dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
@@ -585,8 +593,10 @@ class ResBlockFn(Function):
         p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
         dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
         dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)))) if need[3] else None
-        dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv)) if need[4] else None
-        r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True)
+        dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv, out=_slot_out(s_bqkv, (3 * D,)))) if need[4] else None
+        r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True,
+                     outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
+                           _slot_out(s_bo, (D,)) if need[6] else None))
         dx, dln1w, dln1b = r[0], r[1], r[2]
         dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
         if side is not None:

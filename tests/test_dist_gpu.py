@@ -133,7 +133,7 @@ def test_rccl_single_rank_gradsync_bf16_wire_and_fused_optimizer():
 
         l0 = run(model)
         g0 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        for wire, tol in ((True, 2.0 ** -8), (False, 0.0)):
+        for wire, tol in ((True, 2.0 ** -8), (False, 2.0 ** -20)):  # fp32 wire: exact up to the order of the embedding-table atomics
             net = GradSync(model, compress=wire)
             for _ in range(3):
                 l1 = run(net)
