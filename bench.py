@@ -18,8 +18,10 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # see segclip_amd/__init__.py: keeps the side streams on their own queues
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

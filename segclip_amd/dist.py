@@ -95,6 +95,8 @@ class GradSync(nn.Module):
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def forward(self, *args, **kwargs):
+        if torch.cuda.is_available():
+            self._main = torch.cuda.current_stream()   # the caller's stream: the exchange stream must run beside it
         return self.module(*args, **kwargs)
 
     def no_sync(self):
@@ -169,7 +171,8 @@ class GradSync(nn.Module):
         if flat.is_cuda and nccl:
             from . import ops
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=flat.device)
+                from . import streams  # a stream measured to run beside the main stream (see streams.py)
+                self._comm = streams.side_stream("comm", getattr(self, "_main", None))
             self._comm.wait_stream(torch.cuda.current_stream(flat.device))
             for st in self._bstreams[b]:          # every stream that produced a gradient of this bucket
                 self._comm.wait_stream(st)

@@ -119,11 +119,8 @@ class SegCLIP(SegCLIPPreTrainedModel):
         return config.scope(**self.segclip_config)
 
     def _text_stream(self):
-        st = getattr(self, "_side_stream", None)
-        if st is None or st.device != torch.cuda.current_stream().device:
-            st = torch.cuda.Stream()
-            self.__dict__["_side_stream"] = st
-        return st
+        from .. import streams
+        return streams.side_stream("text")
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, token_type_ids, attention_mask, image, image_seg=None):

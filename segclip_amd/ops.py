@@ -277,15 +277,9 @@ def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0,
     L.check(lib.segclip_attn_bwd(C.byref(d), L.stream()), "attn_bwd")
 
 
-_WGRAD_STREAMS = {}
-
-
 def _wgrad_stream():
-    dev = torch.cuda.current_device()
-    st = _WGRAD_STREAMS.get(dev)
-    if st is None:
-        st = _WGRAD_STREAMS[dev] = torch.cuda.Stream()
-    return st
+    from . import streams
+    return streams.side_stream("wgrad")
 
 
 def interp_pos_table(table, h, w):
