@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--full-loss", action="store_true", help="configs[3]: + superpixel-KL + MAE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N>1 code path (RCCL group, GradSync, barriers) even with one rank: single-GPU check of it")
@@ -58,53 +59,101 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """CPU cores this process can really use: affinity mask and cgroup CPU quota, not os.cpu_count() (a 256-core host
+    with a container quota ran the 256-thread oracle step 400x slower than the 32-thread one: oversubscribed OpenMP)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline_worker(threads):
+    """One thread count of the CPU baseline, in its own process (prints one JSON object)."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import FULL_FLAGS, model_param_shapes, oracle_params
+    spec = synth.SPECS["vitb16"]
+    torch.set_num_threads(threads)
+    B, out = 4, {}
+    for tag, flags in (("contrastive", {}), ("full_loss", FULL_FLAGS)):
+        P = oracle_params(spec, model_param_shapes(spec, flags))
+        batch = synth.synthetic_batch(spec, B, seed=2, with_seg=bool(flags))
+        noise = synth.synthetic_noise(spec, B, seed=2)
+        best, loss = None, None
+        for it in range(4):  # 1 warm-up + 3 timed
+            for p in P.values():
+                p.grad = None
+            t0 = time.perf_counter()
+            loss, _ = so.segclip_forward(batch, P, spec, noise, flags)
+            loss.backward()
+            dt = time.perf_counter() - t0
+            if it and (best is None or dt < best):
+                best = dt
+            if it and dt > 5.0:
+                break          # a slow host: one timed step instead of three keeps the run bounded
+        out[tag] = [B / best, best, float(loss.detach())]
+        print(json.dumps({"partial": out}), flush=True)
+    print(json.dumps({"done": out}), flush=True)
+
+
 def cpu_baseline():
     """Reference CPU path (the oracle = validated CPU restatement of the reference; the reference's Python cannot travel
     to the GPU box) on this host's cores, SURVEY.md 8(d): BASELINE.json configs[0] - ViT-B/16 + 77-token text, batch 4,
     1 step fwd+bwd after 1 warm-up, best of 3 - contrastive-only (the metric's loss) and the full SegCLIP loss, with
-    torch.set_num_threads(all host cores) and, because torch-CPU eager stops scaling long before 100+ threads, with 32
-    threads as well; `value` is the best contrastive-only rate, `cores` the thread count that produced it."""
-    from oracle import segclip_oracle as so
-    from tests.helpers import FULL_FLAGS, model_param_shapes, oracle_params
-    spec = synth.SPECS["vitb16"]
-    host = os.cpu_count() or 1
+    all usable cores (affinity / cgroup quota) and, because torch-CPU eager stops scaling long before 100+ threads, with
+    32 threads as well.  Every thread count runs in its own process under a 90-second limit, so the bench stays
+    bounded on any host; `value` is the best contrastive-only rate, `cores` the thread count that produced it."""
+    import subprocess
+    host, usable = os.cpu_count() or 1, usable_cores()
     try:
         model_name = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         model_name = "unknown"
-    B = 4
-    results = {}
-    budget_t0 = time.perf_counter()
-    for threads in sorted({host, min(host, 32)}, reverse=True):
-        torch.set_num_threads(threads)
-        for tag, flags in (("contrastive", {}), ("full_loss", FULL_FLAGS)):
-            if time.perf_counter() - budget_t0 > 45.0 and (tag, threads) != ("contrastive", host):
-                continue   # bounded: the GPU box is billed for this too
-            P = oracle_params(spec, model_param_shapes(spec, flags))
-            batch = synth.synthetic_batch(spec, B, seed=2, with_seg=bool(flags))
-            noise = synth.synthetic_noise(spec, B, seed=2)
-            best, loss = None, None
-            for it in range(4):  # 1 warm-up + 3 timed
-                for p in P.values():
-                    p.grad = None
-                t0 = time.perf_counter()
-                loss, _ = so.segclip_forward(batch, P, spec, noise, flags)
-                loss.backward()
-                dt = time.perf_counter() - t0
-                if it and (best is None or dt < best):
-                    best = dt
-                if it and dt > 5.0:
-                    break          # a slow host: one timed step instead of three keeps the run bounded
-            results[(tag, threads)] = (B / best, best, float(loss.detach()))
+    results, notes = {}, []
+    for threads in sorted({usable, min(usable, 32)}):
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+        got = None
+        try:
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads)], env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=90, text=True)
+            lines = pr.stdout
+        except subprocess.TimeoutExpired as e:
+            lines = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+            notes.append(f"{threads} threads: stopped at the 90-s limit")
+        for l in lines.splitlines():
+            try:
+                o = json.loads(l)
+                got = o.get("done") or o.get("partial") or got
+            except Exception:
+                pass
+        for tag, v in (got or {}).items():
+            results[(tag, threads)] = tuple(v)
     con = {t: v for (tag, t), v in results.items() if tag == "contrastive"}
     full = {t: v for (tag, t), v in results.items() if tag == "full_loss"}
+    if not con:
+        return {"value": None, "unit": "pairs/s", "cores": usable, "host_cores": host, "cpu": model_name, "kind": "port",
+                "sample": "no CPU baseline finished within the limit: " + "; ".join(notes)}
     bt = max(con, key=lambda t: con[t][0])
-    out = {"value": round(con[bt][0], 3), "unit": "pairs/s", "cores": bt, "host_cores": host, "cpu": model_name,
-           "kind": "port",
+    out = {"value": round(con[bt][0], 3), "unit": "pairs/s", "cores": bt, "usable_cores": usable, "host_cores": host,
+           "cpu": model_name, "kind": "port",
            "sample": f"oracle (CPU restatement of the reference, torch {torch.__version__} fp32), BASELINE configs[0]: "
-                     f"ViT-B/16 B=4 fwd+bwd, 1 warm-up + best of 3; contrastive-only: "
+                     f"ViT-B/16 B=4 fwd+bwd, 1 warm-up + best of 3, one process per thread count; contrastive-only: "
                      + ", ".join(f"{t} threads {v[1]:.2f} s/step" for t, v in sorted(con.items()))
-                     + ("; full loss: " + ", ".join(f"{t} threads {v[1]:.2f} s/step" for t, v in sorted(full.items())) if full else ""),
+                     + ("; full loss: " + ", ".join(f"{t} threads {v[1]:.2f} s/step" for t, v in sorted(full.items())) if full else "")
+                     + ("; " + "; ".join(notes) if notes else ""),
            "loss": round(con[bt][2], 6)}
     if full:
         ft = max(full, key=lambda t: full[t][0])
@@ -131,6 +180,9 @@ def respawn(a):
 
 def main():
     a = parse()
+    if a.cpu_baseline_worker:
+        cpu_baseline_worker(a.cpu_baseline_worker)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -233,7 +285,9 @@ def main():
                     "condition": "as in the timed region (text tower concurrent on a second stream)",
                     "achieved_isolated": round(fiso / tiso / 1e12, 1),
                     "traffic": traffic, "traffic_source": tsrc,
-                    "algorithmic_flops_per_launch": round(fsum / len(rec)), "launches_per_step": len(rec),
+                    "algorithmic_flops_per_launch": round(fsum / len(rec)),
+                    "algorithmic_bytes_per_launch": round(sum(r[3] for r in rec) / len(rec)),
+                    "launches_per_step": len(rec),
                     "avg_launch_us": round(tsum / len(rec) * 1e6, 1),
                     "gemm_time_per_step_ms": round(tsum * 1e3, 2),
                     "large_gemm_tflops": round(sum(r[1] for r in big) / max(sum(r[0] for r in big), 1e-9) / 1e12, 1),

@@ -25,7 +25,7 @@ class _GemmProfile:
     """Optional per-launch timing of the dominant (GEMM) kernel with HIP events on the launch stream
     (bench.py's roofline leg).  Off by default; adds two event records per launch when enabled."""
     enabled = False
-    records = []  # (start_event, end_event, flops, is_bf16)
+    records = []  # (start_event, end_event, flops, is_bf16, algorithmic bytes)
 
     @classmethod
     def start(cls):
@@ -35,7 +35,7 @@ class _GemmProfile:
     def stop(cls):
         cls.enabled = False
         torch.cuda.synchronize()
-        out = [(s.elapsed_time(e) * 1e-3, f, b) for s, e, f, b in cls.records]
+        out = [(s.elapsed_time(e) * 1e-3, f, b, nb) for s, e, f, b, nb in cls.records]
         cls.records = []
         return out
 
@@ -92,7 +92,11 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
         e0.record()
         L.check(lib.segclip_gemm(C.byref(d), L.stream()), "gemm")
         e1.record()
-        _GemmProfile.records.append((e0, e1, 2.0 * M * N * K * nb1 * nb2, B.dtype == torch.bfloat16))
+        nz = nb1 * nb2
+        nbytes = nz * (M * K * A.element_size() + N * K * B.element_size() + M * N * Cc.element_size()
+                       + (M * N * residual.element_size() if residual is not None else 0)
+                       + (M * N * aux.element_size() if aux is not None else 0))   # operands read once + outputs written once
+        _GemmProfile.records.append((e0, e1, 2.0 * M * N * K * nz, B.dtype == torch.bfloat16, nbytes))
         return Cc
     L.check(lib.segclip_gemm(C.byref(d), L.stream()), "gemm")
     return Cc

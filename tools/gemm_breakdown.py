@@ -22,7 +22,7 @@ def wrapped(A, B, Cc, M, N, K, sa, sb, ldc, **kw):
 ops.p_gemm = wrapped
 ops._GemmProfile.start(); step(); rec = ops._GemmProfile.stop()
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for s, (t, f, _) in zip(shapes, rec):
+for s, (t, f, _, _nb) in zip(shapes, rec):
     a = agg[s]; a[0] += 1; a[1] += t; a[2] += f
 tot = sum(a[1] for a in agg.values())
 print(f"total GEMM time {tot*1e3:.2f} ms, {len(rec)} launches")
