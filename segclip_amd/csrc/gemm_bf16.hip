@@ -281,6 +281,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(Args g) {
   }
 }
 
+#if GB_PART == 4
 // C = alpha * sum_s slab[s]  (split-K combine; deterministic order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, void* C, int64_t M, int64_t N, int64_t ldc,
                                      int64_t nb2, int64_t bsC1, int64_t bsC2, int splits, int64_t nz, float alpha,
@@ -325,7 +326,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
     reinterpret_cast<f32x4*>(C)[i] = v;
 }
 
+#endif  // GB_PART == 4 (reduction kernels)
 }  // namespace
+
+// Compiled once per GB_PART (build.sh), like gemm_bf16_p8.hip: parts 0..3 hold the four kernel instances (fp32 / bf16
+// left operand x aligned / ragged) of one operand layout <A_KS = part>>1, B_KS = part&1> behind a launcher; part 4 is
+// the split-K reduction kernels and the host-side dispatcher.
+#ifndef GB_PART
+#error "compile with -DGB_PART=0..4 (see build.sh)"
+#endif
+#define GB_LAUNCHER(NAME, AK, BKS)                                                                              \
+  void NAME(bool a_f32, bool fast, dim3 grid, hipStream_t stream, const void* args) {                           \
+    const Args g = *reinterpret_cast<const Args*>(args);                                                        \
+    if (a_f32) {                                                                                                \
+      if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, true, true>), grid, dim3(NT), 0, stream, g);      \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, true, false>), grid, dim3(NT), 0, stream, g);          \
+    } else {                                                                                                    \
+      if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, false, true>), grid, dim3(NT), 0, stream, g);     \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, false, false>), grid, dim3(NT), 0, stream, g);         \
+    }                                                                                                           \
+  }
+#if GB_PART == 0
+GB_LAUNCHER(segclip_gb_launch_ff, false, false)
+#elif GB_PART == 1
+GB_LAUNCHER(segclip_gb_launch_fk, false, true)
+#elif GB_PART == 2
+GB_LAUNCHER(segclip_gb_launch_kf, true, false)
+#elif GB_PART == 3
+GB_LAUNCHER(segclip_gb_launch_kk, true, true)
+#endif
+
+#if GB_PART == 4
+void segclip_gb_launch_ff(bool, bool, dim3, hipStream_t, const void*);
+void segclip_gb_launch_fk(bool, bool, dim3, hipStream_t, const void*);
+void segclip_gb_launch_kf(bool, bool, dim3, hipStream_t, const void*);
+void segclip_gb_launch_kk(bool, bool, dim3, hipStream_t, const void*);
 
 bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t kper, int64_t nb,
                                hipStream_t stream);
@@ -439,16 +474,10 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     return SEGCLIP_ERR_UNSUPPORTED;
   }
   if (!launched) {
-#define LAUNCH(AK, BKS, AF)                                                                                         \
-  do {                                                                                                              \
-    if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, AF, true>), grid, dim3(NT), 0, stream, g);              \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKS, AF, false>), grid, dim3(NT), 0, stream, g);                  \
-  } while (0)
-  if (!a_ks && !b_ks) { if (a_f32) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
-  else if (!a_ks && b_ks) { if (a_f32) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-  else if (a_ks && b_ks) { if (a_f32) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-  else { if (a_f32) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
-#undef LAUNCH
+    if (!a_ks && !b_ks) segclip_gb_launch_ff(a_f32, fast, grid, stream, &g);
+    else if (!a_ks && b_ks) segclip_gb_launch_fk(a_f32, fast, grid, stream, &g);
+    else if (a_ks && b_ks) segclip_gb_launch_kk(a_f32, fast, grid, stream, &g);
+    else segclip_gb_launch_kf(a_f32, fast, grid, stream, &g);
   }
   SEGCLIP_CHECK_LAUNCH("gemm_bf16");
   if (d->colsum) {
@@ -470,3 +499,4 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   }
   return 0;
 }
+#endif  // GB_PART == 4

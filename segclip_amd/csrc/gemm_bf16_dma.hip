@@ -252,6 +252,44 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kern
 
 }  // namespace
 
+// Compiled once per DMA_PART (build.sh), like gemm_bf16_p8.hip: parts 0..3 hold the kernel instances of one operand
+// layout <A_KS = part>>1, B_KS = part&1> behind a launcher, part 4 the host-side dispatcher.
+#ifndef DMA_PART
+#error "compile with -DDMA_PART=0..4 (see build.sh)"
+#endif
+// variant: 0 = 256x128 tile, 1 = 256x256 tile, 2 = 128x128 tile / 4 waves, 3 = 256x128 tile with a 3-stage ring (2, 3:
+// only with -DSEGCLIP_GEMM_EXPERIMENTS)
+#ifdef SEGCLIP_GEMM_EXPERIMENTS
+#define DMA_EXP(AK, BKS)                                                                                        \
+  if (variant == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128, 128, 4>), grid, dim3(256), 0, stream, g);      \
+  else if (variant == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8, 3>), grid, dim3(512), 0, stream, g); \
+  else
+#else
+#define DMA_EXP(AK, BKS)
+#endif
+#define DMA_LAUNCHER(NAME, AK, BKS)                                                                             \
+  void NAME(int variant, dim3 grid, hipStream_t stream, const void* args) {                                     \
+    const Args g = *reinterpret_cast<const Args*>(args);                                                        \
+    DMA_EXP(AK, BKS)                                                                                            \
+    if (variant == 1) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 256, 8>), grid, dim3(512), 0, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8>), grid, dim3(512), 0, stream, g);       \
+  }
+#if DMA_PART == 0
+DMA_LAUNCHER(segclip_dma_launch_ff, false, false)
+#elif DMA_PART == 1
+DMA_LAUNCHER(segclip_dma_launch_fk, false, true)
+#elif DMA_PART == 2
+DMA_LAUNCHER(segclip_dma_launch_kf, true, false)
+#elif DMA_PART == 3
+DMA_LAUNCHER(segclip_dma_launch_kk, true, true)
+#endif
+
+#if DMA_PART == 4
+void segclip_dma_launch_ff(int, dim3, hipStream_t, const void*);
+void segclip_dma_launch_fk(int, dim3, hipStream_t, const void*);
+void segclip_dma_launch_kf(int, dim3, hipStream_t, const void*);
+void segclip_dma_launch_kk(int, dim3, hipStream_t, const void*);
+
 // tile-count heuristic: the 256x256 tile unless it leaves the 256 CUs badly quantised and 256x128 does not
 static int pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits) {
   constexpr int BM = 256;
@@ -286,9 +324,13 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   // loses 5-15 % on long-K dgrads and every split-K wgrad; inside the training step (text tower concurrent on a
   // second stream) a shape-based choice measured 58.4 vs 58.2 ms, i.e. no gain, so the 256-wide tiles stay the
   // default and SEGCLIP_GEMM_TILE=128 selects this variant for experiments.
+#ifdef SEGCLIP_GEMM_EXPERIMENTS  // build.sh -DSEGCLIP_GEMM_EXPERIMENTS: 8 more kernel instances (+3 min of hipcc time)
   static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const bool small = force_tile == 128;
   const bool three = force_tile == 3;  // experiment: 256x128 tiles with a 3-stage ring (96 KiB in flight)
+#else
+  constexpr bool small = false, three = false;
+#endif
   const int bn = (small || three) ? 128 : pick_bn(d, nb * splits);
   const int bm = small ? 128 : 256;
   g.nbx = (int)cdiv(d->N, bn);
@@ -305,17 +347,11 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
     if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
-#define GO(AK, BKS)                                                                                               \
-  do {                                                                                                            \
-    if (small) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128, 128, 4>), grid, dim3(256), 0, stream, g);   \
-    else if (bn == 256) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 256, 8>), grid, dim3(512), 0, stream, g); \
-    else if (three) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8, 3>), grid, dim3(512), 0, stream, g); \
-    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8>), grid, dim3(512), 0, stream, g);         \
-  } while (0)
-  if (!a_ks && !b_ks) GO(false, false);
-  else if (!a_ks && b_ks) GO(false, true);
-  else if (a_ks && b_ks) GO(true, true);
-  else GO(true, false);
-#undef GO
+  const int variant = small ? 2 : three ? 3 : bn == 256 ? 1 : 0;
+  if (!a_ks && !b_ks) segclip_dma_launch_ff(variant, grid, stream, &g);
+  else if (!a_ks && b_ks) segclip_dma_launch_fk(variant, grid, stream, &g);
+  else if (a_ks && b_ks) segclip_dma_launch_kk(variant, grid, stream, &g);
+  else segclip_dma_launch_kf(variant, grid, stream, &g);
   return true;
 }
+#endif  // DMA_PART == 4

@@ -326,6 +326,46 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
 
 }  // namespace
 
+// The file is compiled once per P8_PART (segclip_amd/csrc/build.sh) so that the four operand-layout instances - each
+// carries every epilogue variant and takes over a minute of hipcc time - build in parallel:
+//   P8_PART 0..3 : kernel instance <A_KS = part>>1, B_KS = part&1> and its launcher
+//   P8_PART 4    : the host-side dispatcher below (no device code)
+//   P8_PART 5    : the main-loop ablation instances (only with -DSEGCLIP_P8_ABLATIONS; tools/bench_gemm_abl.py)
+#ifndef P8_PART
+#error "compile with -DP8_PART=0..5 (see build.sh)"
+#endif
+#define P8_LAUNCHER(NAME, ...)                                                      \
+  void NAME(dim3 grid, hipStream_t stream, const void* args) {                      \
+    const Args g = *reinterpret_cast<const Args*>(args);                            \
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<__VA_ARGS__>), grid, dim3(512), 0, stream, g); \
+  }
+#if P8_PART == 0
+P8_LAUNCHER(segclip_p8_launch_ff, false, false)
+#elif P8_PART == 1
+P8_LAUNCHER(segclip_p8_launch_fk, false, true)
+#elif P8_PART == 2
+P8_LAUNCHER(segclip_p8_launch_kf, true, false)
+#elif P8_PART == 3
+P8_LAUNCHER(segclip_p8_launch_kk, true, true)
+#elif P8_PART == 5
+P8_LAUNCHER(segclip_p8_launch_abl1, false, false, 1)
+P8_LAUNCHER(segclip_p8_launch_abl2, false, false, 2)
+P8_LAUNCHER(segclip_p8_launch_abl3, false, false, 3)
+P8_LAUNCHER(segclip_p8_launch_abl4, false, false, 4)
+#endif
+
+#if P8_PART == 4
+void segclip_p8_launch_ff(dim3, hipStream_t, const void*);
+void segclip_p8_launch_fk(dim3, hipStream_t, const void*);
+void segclip_p8_launch_kf(dim3, hipStream_t, const void*);
+void segclip_p8_launch_kk(dim3, hipStream_t, const void*);
+#ifdef SEGCLIP_P8_ABLATIONS
+void segclip_p8_launch_abl1(dim3, hipStream_t, const void*);
+void segclip_p8_launch_abl2(dim3, hipStream_t, const void*);
+void segclip_p8_launch_abl3(dim3, hipStream_t, const void*);
+void segclip_p8_launch_abl4(dim3, hipStream_t, const void*);
+#endif
+
 // Launch the phase-pipelined kernel for problems tiled 256x256.  `args_` is prepared by the caller (gemm_bf16.hip);
 // returns false when the shape does not meet this kernel's preconditions.
 bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t kper, int64_t nb,
@@ -355,14 +395,18 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
     if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
+#ifdef SEGCLIP_P8_ABLATIONS
   static const int abl = [] { const char* e = getenv("SEGCLIP_P8_ABL"); return e ? atoi(e) : 0; }();
-  if (!a_ks && !b_ks && abl == 1) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 1>), grid, dim3(512), 0, stream, g);
-  else if (!a_ks && !b_ks && abl == 2) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 2>), grid, dim3(512), 0, stream, g);
-  else if (!a_ks && !b_ks && abl == 3) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 3>), grid, dim3(512), 0, stream, g);
-  else if (!a_ks && !b_ks && abl == 4) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, 4>), grid, dim3(512), 0, stream, g);
-  else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false>), grid, dim3(512), 0, stream, g);
-  else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, true>), grid, dim3(512), 0, stream, g);
-  else if (a_ks && b_ks) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, true>), grid, dim3(512), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false>), grid, dim3(512), 0, stream, g);
+  if (!a_ks && !b_ks && abl >= 1 && abl <= 4) {
+    (abl == 1 ? segclip_p8_launch_abl1 : abl == 2 ? segclip_p8_launch_abl2 : abl == 3 ? segclip_p8_launch_abl3
+                                                                             : segclip_p8_launch_abl4)(grid, stream, &g);
+    return true;
+  }
+#endif
+  if (!a_ks && !b_ks) segclip_p8_launch_ff(grid, stream, &g);
+  else if (!a_ks && b_ks) segclip_p8_launch_fk(grid, stream, &g);
+  else if (a_ks && b_ks) segclip_p8_launch_kk(grid, stream, &g);
+  else segclip_p8_launch_kf(grid, stream, &g);
   return true;
 }
+#endif  // P8_PART == 4
