@@ -18,6 +18,9 @@ trust_weight_shadows : False: every training forward re-casts all GEMM weights t
                 fused optimizer maintains the bf16 copies itself)
 attn_fp8      : bf16 mode only: the self-attention FORWARD of the residual blocks runs Q K^T and P V on the e4m3 MFMA
                 (BASELINE configs[4]; per-token scales for Q/K, per-chunk scale for V); backward stays bf16
+fuse_res_stack: consecutive residual blocks of a tower run as ONE autograd node (ops.ResStackFn) instead of one per block
+bf16_resgrad  : bf16 mode, inside ResStackFn: the residual-stream gradient travels between the LayerNorm backwards as
+                one bf16 tensor (10 instead of 16 bytes per element); False keeps it fp32
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -30,7 +33,7 @@ import types
 import torch
 
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
-                 trust_weight_shadows=False, attn_fp8=False)
+                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True)
 _tls = threading.local()
 
 

@@ -35,11 +35,13 @@ _NO_EXCHANGE = bool(int(os.environ.get("SEGCLIP_GRADSYNC_NOEXCHANGE", "0")))  # 
 
 class _Slot:
     """A parameter's place in a flat gradient bucket."""
-    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner", "taken_pass", "ptr")
+    __slots__ = ("bucket", "offset", "numel", "shape", "param", "owner", "taken_pass", "ptr", "fwd_pass", "fwd_uses", "reported_pass")
 
     def __init__(self, bucket, offset, p, owner):
         self.bucket, self.offset, self.numel, self.shape = bucket, offset, p.numel(), tuple(p.shape)
         self.taken_pass = -1
+        self.fwd_pass, self.fwd_uses = -1, 0
+        self.reported_pass = -1
         self.ptr = owner._flat[bucket].data_ptr() + 4 * offset   # address of the slot (hook fast path: no view objects)
         self.param = weakref.ref(p)
         self.owner = weakref.ref(owner)
@@ -47,6 +49,20 @@ class _Slot:
     def view(self):
         o = self.owner()
         return o._flat[self.bucket][self.offset:self.offset + self.numel].view(self.shape)
+
+    def note_forward_use(self):
+        """Called by the block forwards: counts how often the parameter is used in the current pass (a parameter used
+        twice must not be published before autograd has summed both contributions)."""
+        o = self.owner()
+        if o is None:
+            return
+        if self.fwd_pass != o._pass_id:
+            self.fwd_pass, self.fwd_uses = o._pass_id, 0
+        self.fwd_uses += 1
+
+    def single_use(self):
+        o = self.owner()
+        return o is not None and self.fwd_pass == o._pass_id and self.fwd_uses == 1
 
     def out_buffer(self):
         """Fresh view to be used as the OUTPUT of a gradient kernel, or None when the parameter already
@@ -129,6 +145,9 @@ class GradSync(nn.Module):
         if slot is None:   # became used after the layout was frozen: exchanged on its own at the end
             self._late.append(p)
             return
+        if slot.reported_pass == self._pass_id:
+            return   # published early by ops.ResStackFn; autograd still runs the accumulate hook for the (undefined) grad
+        slot.reported_pass = self._pass_id
         g = p.grad
         if g.is_cuda:
             # the text tower's backward runs on its own stream: a bucket may hold gradients of several streams

@@ -21,6 +21,12 @@ class ResidualAttentionBlock(nn.Module):
                                               ("c_proj", nn.Linear(d_model * 4, d_model))]))
         self.ln_2 = LayerNorm(d_model)
 
+    def block_params(self):
+        """The 12 parameters in ops.ResBlockFn / ops.ResStackFn order."""
+        return (self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight, self.attn.in_proj_bias,
+                self.attn.out_proj.weight, self.attn.out_proj.bias, self.ln_2.weight, self.ln_2.bias,
+                self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias)
+
     def forward_nld(self, x, causal):
         return ops.ResBlockFn.apply(x, self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight,
                                     self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias,
@@ -44,7 +50,12 @@ class TextTransformer(nn.Module):
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
 
     def forward_nld(self, x, causal=True):
-        for blk in self.resblocks:
+        blocks = list(self.resblocks)
+        if config.fuse_res_stack and len(blocks) > 1:   # the whole tower as one autograd node (ops.ResStackFn)
+            b0 = blocks[0]
+            return ops.res_stack(x, [b.block_params() for b in blocks], b0.n_head, causal, ops.ACT_QUICK_GELU,
+                                 b0.ln_1.eps, config.compute_dtype)
+        for blk in blocks:
             x = blk.forward_nld(x, causal)
         return x
 

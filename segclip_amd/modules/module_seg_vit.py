@@ -48,6 +48,12 @@ class ResidualAttentionBlock(nn.Module):
         self.ln_2 = LayerNorm(d_model)
         self.causal = False
 
+    def block_params(self):
+        """The 12 parameters in ops.ResBlockFn / ops.ResStackFn order."""
+        return (self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight, self.attn.in_proj_bias,
+                self.attn.out_proj.weight, self.attn.out_proj.bias, self.ln_2.weight, self.ln_2.bias,
+                self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias)
+
     def forward(self, x, attn_mask=None, video_frame=-1):
         if attn_mask is not None and not callable(attn_mask):
             raise NotImplementedError("padding masks are only reachable from the text-MAE branch (out of scope)")
@@ -236,22 +242,33 @@ class SegViT(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    @staticmethod
+    def _run_blocks(seq, x):
+        """nn.Sequential of ResidualAttentionBlocks as ONE autograd node (ops.ResStackFn) when there are several."""
+        blocks = list(seq) if isinstance(seq, nn.Sequential) else None
+        if (config.fuse_res_stack and blocks and len(blocks) > 1
+                and all(isinstance(b, ResidualAttentionBlock) and not b.causal for b in blocks)):
+            b0 = blocks[0]
+            return ops.res_stack(x.float(), [b.block_params() for b in blocks], b0.n_head, False, ops.ACT_QUICK_GELU,
+                                 b0.ln_1.eps, config.compute_dtype)
+        return seq(x)
+
     def forward_patches(self, x_):
         """Body of forward() on the patch tokens only: x_ (B,T,D) NLD without the CLS row.
         Returns (x (B,1+T',D) NLD with the pooled CLS prepended, mid_states)."""
         mid_states = {"hidden": None, "attns": []}
-        x_ = self.layers0(x_)
+        x_ = self._run_blocks(self.layers0, x_)
         if self.patch_len ** 2 != x_.size(1) and 4 * (self.patch_len ** 2) != x_.size(1):  # MAE branch
             sx_, hard_attn_2, soft_attn_2, _ = self.semantic_layer2(x_)
             x_ = self.reconstruct_layer2(sx_, hard_attn_2)
-            x_ = self.layers_mae2(x_)
+            x_ = self._run_blocks(self.layers_mae2, x_)
             mid_states["hidden"] = x_
             cls = torch.mean(x_, dim=1, keepdim=True)
             x = torch.cat([cls, x_], dim=1)
         else:
             mid_states["hidden"] = x_
             x_, hard_attn_2, soft_attn_2, _ = self.semantic_layer2(x_)
-            x_ = self.layers2(x_)
+            x_ = self._run_blocks(self.layers2, x_)
             cls = torch.max(x_, dim=1, keepdim=True)[0]
             x = torch.cat([cls, x_], dim=1)
             mid_states["attns"].append({"soft_attn": soft_attn_2, "hard_attn": hard_attn_2})

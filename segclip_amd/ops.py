@@ -494,9 +494,114 @@ class ActFn(Function):
         return dx, None
 
 
+def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
+    """One pre-LN residual block on the (B*T, D) fp32 stream: returns (x_out (B*T, D) fp32, tensors saved for backward)."""
+    ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = P
+    M, D = x2.shape
+    hd = D // n_head
+    for w in P:
+        sl = _slot_of(w)
+        if sl is not None:
+            sl.note_forward_use()
+    y1, mean1, rstd1 = p_ln_fwd(x2, ln1w, ln1b, eps, act_dtype)
+    wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (wqkv, wo, wfc, wpr))
+    qkv, _ = p_linear(y1, wqkv_c, bqkv)
+    o = _empty((M, D), act_dtype, x2)
+    from . import config as _cfg
+    ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, (T * 3 * D, 3 * D), (T * 3 * D, 3 * D),
+                    (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D,
+                    fp8=bool(_cfg.attn_fp8) and act_dtype == torch.bfloat16, klen=klen)
+    stats = p_attn_fwd(ad, x2)
+    x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
+    y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
+    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True)
+    xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
+    saved = (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c)
+    return xo, saved
+
+
+N_SAVED = 19
+
+
+def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain):
+    """Hand-scheduled backward of one block.  g: fp32 (M, D) gradient of the block output or None; g16: its bf16 copy or
+    None.  need[i]: gradient wanted for forward input i (0 = x, 1..12 = the parameters in forward order).
+    chain=False: fp32 residual gradient in and out (plus the bf16 copy the LayerNorm backward emits for free).
+    chain=True (bf16 mode inside ResStackFn): the residual gradient travels between the LayerNorm backwards as ONE bf16
+    tensor (read 2 + written 2 bytes per element instead of 4 + 4 + 2): g may be None, returns dx fp32 = None.
+    -> (dx fp32 or None, dx bf16 or None, the 12 parameter gradients)"""
+    (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c) = saved
+    B, T, D, n_head, causal, act, act_dtype = cfg
+    M = B * T
+    hd = D // n_head
+    bf = act_dtype == torch.bfloat16
+    # bf16 mode: the residual-stream gradients feed the GEMMs as bf16 copies (all GEMMs then run on the LDS-DMA
+    # kernels and read half the bytes); the copy of dx comes for free out of the LayerNorm backward.
+    if bf and g16 is None:
+        g16 = p_cast(g, act_dtype)
+    if not bf:
+        g16 = g
+    res_in = g16 if chain else g
+    rdt = act_dtype if chain else torch.float32
+    # The weight gradients do not feed the data-gradient chain: optionally (config.overlap_wgrad) they are enqueued
+    # on a second HIP stream.
+    from . import config as _cfg
+    main = torch.cuda.current_stream()
+    side = _wgrad_stream() if _cfg.overlap_wgrad else None
+    sq, so, sf, sp = gslots  # weight gradients land directly in their all-reduce bucket (segclip_amd/dist.py)
+    F4 = wfc_c.shape[0]
+    s_ln1w, s_ln1b, s_bqkv, s_bo, s_ln2w, s_ln2b, s_bfc, s_bpr = vslots   # ... and so do the 8 vector gradients
+
+    def on_side(fn, *deps):
+        if side is None:
+            return fn()
+        side.wait_stream(main)           # operands produced on the main stream are ready
+        with torch.cuda.stream(side):
+            out = fn()
+        if out is not None:
+            out.record_stream(main)
+        return out
+
+    # ---- MLP
+    du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
+                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None)  # (dy c_proj)*act'(u), colsum
+    dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)))) if need[11] else None
+    dy2 = p_dgrad(du, wfc_c, act_dtype)
+    dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)))) if need[9] else None
+    two = bf and not chain   # fp32 dx + its bf16 copy
+    r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=res_in, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
+                 outs=(_slot_out(s_ln2w, (D,)) if need[7] else None, _slot_out(s_ln2b, (D,)) if need[8] else None,
+                       _slot_out(s_bpr, (D,)) if need[12] else None))
+    dx1, dln2w, dln2b = r[0], r[1], r[2]
+    dx1_16 = r[3] if two else dx1
+    dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
+    # ---- attention
+    do = p_dgrad(dx1_16, wo_c, act_dtype)
+    dwo = on_side(lambda: p_wgrad(dx1_16, o, out=_slot_out(so, (D, D)))) if need[5] else None
+    dqkv = _empty((M, 3 * D), act_dtype, x2)
+    s3 = (T * 3 * D, 3 * D)
+    ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
+                    0, D, 2 * D, klen=klen)
+    part = _empty((B, 3 * D), torch.float32, x2) if (bf and need[4]) else None  # in_proj bias gradient per sample
+    p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
+    dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
+    dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)))) if need[3] else None
+    dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv, out=_slot_out(s_bqkv, (3 * D,)))) if need[4] else None
+    r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
+                 outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
+                       _slot_out(s_bo, (D,)) if need[6] else None))
+    dln1w, dln1b = r[1], r[2]
+    dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
+    if side is not None:
+        main.wait_stream(side)  # every buffer the side stream read may be recycled after this point
+    dx32 = None if chain else r[0]
+    dx16 = r[0] if chain else (r[3] if two else None)
+    return dx32, dx16, (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr)
+
+
 class ResBlockFn(Function):
-    """One pre-LN residual attention block as ONE autograd node (modules/module_seg_vit.py:162-196,
-    modules/module_clip_ttransformer.py:20-52, modules/module_mae.py:185-201):
+    """Fused pre-LN residual attention block (modules/module_clip_ttransformer.py:20-37,
+    module_seg_vit.py:175-196, module_mae.py:185-201):
         x += out_proj(MHA(LN1 x));  x += c_proj(act(c_fc(LN2 x)))
     x (B,T,D) fp32 residual stream.  Backward is hand-scheduled: residual-gradient adds are fused into
     the LayerNorm backward, act' into the c_proj dgrad epilogue, and no gradient is re-read."""
@@ -505,24 +610,10 @@ class ResBlockFn(Function):
     def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr, n_head, causal, act, eps,
                 act_dtype, klen=None):
         B, T, D = x.shape
-        M = B * T
-        x2 = x.contiguous().view(M, D)
-        hd = D // n_head
-        y1, mean1, rstd1 = p_ln_fwd(x2, ln1w, ln1b, eps, act_dtype)
-        wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (wqkv, wo, wfc, wpr))
-        qkv, _ = p_linear(y1, wqkv_c, bqkv)
-        o = _empty((M, D), act_dtype, x)
-        from . import config as _cfg
-        ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, (T * 3 * D, 3 * D), (T * 3 * D, 3 * D),
-                        (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D,
-                        fp8=bool(_cfg.attn_fp8) and act_dtype == torch.bfloat16, klen=klen)
-        stats = p_attn_fwd(ad, x)
-        x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
-        y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
-        h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True)
-        xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
-        ctx.save_for_backward(x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2,
-                              wfc_c, u, h, wpr_c)
+        x2 = x.contiguous().view(B * T, D)
+        P = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr)
+        xo, saved = _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen)
+        ctx.save_for_backward(*saved)
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
         ctx.klen = klen
         ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
@@ -531,79 +622,98 @@ class ResBlockFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h,
-         wpr_c) = ctx.saved_tensors
         B, T, D, n_head, causal, act, act_dtype = ctx.cfg
         M = B * T
-        hd = D // n_head
         st = getattr(g, "_segclip_bf16", None)  # bf16 copy left by the next block's LayerNorm backward (same object)
         if st is not None and (st.numel() != g.numel() or st.device != g.device or not g.is_contiguous()):
             st = None
         g = g.contiguous().view(M, D)
-        need = ctx.needs_input_grad
-        bf = act_dtype == torch.bfloat16
-        # bf16 mode: the fp32 residual-stream gradients feed the GEMMs as bf16 copies (all GEMMs then run on the
-        # LDS-DMA kernel and read half the bytes); the copy of dx comes for free out of the LayerNorm backward and
-        # is handed to the next block through a side channel on the gradient tensor.
-        g16 = g
-        if bf:
-            g16 = st.view(M, D) if st is not None else p_cast(g, act_dtype)
-        # The weight gradients do not feed the data-gradient chain: they are enqueued on a second HIP stream and
-        # run concurrently with the dgrad / LayerNorm / attention kernels of the chain (their tiles fill the CUs
-        # that the chain's partial last rounds and store phases leave idle).
-        from . import config as _cfg
-        main = torch.cuda.current_stream()
-        side = _wgrad_stream() if _cfg.overlap_wgrad else None
-        sq, so, sf, sp = ctx.gslots  # weight gradients land directly in their all-reduce bucket (segclip_amd/dist.py)
-        F4 = wfc_c.shape[0]
-        s_ln1w, s_ln1b, s_bqkv, s_bo, s_ln2w, s_ln2b, s_bfc, s_bpr = ctx.vslots   # ... and so do the 8 vector gradients
-
-        def on_side(fn, *deps):
-            if side is None:
-                return fn()
-            side.wait_stream(main)           # operands produced on the main stream are ready
-            with torch.cuda.stream(side):
-                out = fn()
-            if out is not None:
-                out.record_stream(main)
-            return out
-
-        # ---- MLP
-        du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
-                           colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None)  # (dy c_proj)*act'(u), colsum
-        dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)))) if need[11] else None
-        dy2 = p_dgrad(du, wfc_c, act_dtype)
-        dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)))) if need[9] else None
-        r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True,
-                     outs=(_slot_out(s_ln2w, (D,)) if need[7] else None, _slot_out(s_ln2b, (D,)) if need[8] else None,
-                           _slot_out(s_bpr, (D,)) if need[12] else None))
-        dx1, dln2w, dln2b = r[0], r[1], r[2]
-        dx1_16 = r[3] if bf else dx1
-        dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
-        # ---- attention
-        do = p_dgrad(dx1_16, wo_c, act_dtype)
-        dwo = on_side(lambda: p_wgrad(dx1_16, o, out=_slot_out(so, (D, D)))) if need[5] else None
-        dqkv = _empty((M, 3 * D), act_dtype, g)
-        s3 = (T * 3 * D, 3 * D)
-        ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
-                        0, D, 2 * D, klen=ctx.klen)
-        part = _empty((B, 3 * D), torch.float32, g) if (bf and need[4]) else None  # in_proj bias gradient per sample
-        p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
-        dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
-        dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)))) if need[3] else None
-        dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv, out=_slot_out(s_bqkv, (3 * D,)))) if need[4] else None
-        r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True,
-                     outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
-                           _slot_out(s_bo, (D,)) if need[6] else None))
-        dx, dln1w, dln1b = r[0], r[1], r[2]
-        dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
-        if side is not None:
-            main.wait_stream(side)  # every buffer the side stream read may be recycled after this point
+        g16 = st.view(M, D) if (st is not None and act_dtype == torch.bfloat16) else None
+        dx, dx16, grads = _resblock_bwd(ctx.saved_tensors, ctx.cfg, ctx.klen, ctx.gslots, ctx.vslots,
+                                        ctx.needs_input_grad, g, g16, False)
         dx = dx.view(B, T, D)
-        if bf:
-            dx._segclip_bf16 = r[3].view(B, T, D)
-        return (dx, dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr, None,
-                None, None, None, None, None)
+        if dx16 is not None:
+            dx._segclip_bf16 = dx16.view(B, T, D)
+        return (dx,) + grads + (None, None, None, None, None, None)
+
+
+class ResStackFn(Function):
+    """N consecutive ResBlockFn blocks as ONE autograd node (the towers: 10 + 2 vision blocks, 12 text blocks).  Inside
+    the node the gradients travel between the blocks as plain tensors, so in bf16 mode (config.bf16_resgrad) the
+    residual-stream gradient is a single bf16 tensor per LayerNorm backward (10 instead of 16 bytes per element); the
+    node's own input / output gradients stay fp32.  With segclip_amd.dist.GradSync active, each block's parameter
+    gradients are published (p.grad = bucket slot, ready hook) as soon as the block's backward has been enqueued, not
+    when the whole stack returns, so the bucket all-reduces keep overlapping with the rest of the backward.
+    inputs: x, n_head, causal, act, eps, act_dtype, klen, chain, then 12 parameters per block."""
+
+    NP = 12
+
+    @staticmethod
+    def forward(ctx, x, n_head, causal, act, eps, act_dtype, klen, chain, *params):
+        B, T, D = x.shape
+        nblk = len(params) // ResStackFn.NP
+        cur = x.contiguous().view(B * T, D)
+        saved = []
+        for b in range(nblk):
+            cur, sv = _resblock_fwd(cur, params[b * 12:(b + 1) * 12], B, T, n_head, causal, act, eps, act_dtype, klen)
+            saved.extend(sv)
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
+        ctx.klen, ctx.nblk = klen, nblk
+        ctx.chain = bool(chain) and act_dtype == torch.bfloat16
+        ctx.params = params
+        ctx.slots = tuple(_slot_of(w) for w in params)
+        return cur.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, D, n_head, causal, act, act_dtype = ctx.cfg
+        M, nblk = B * T, ctx.nblk
+        bf = act_dtype == torch.bfloat16
+        st = getattr(g, "_segclip_bf16", None)
+        if st is not None and (st.numel() != g.numel() or st.device != g.device or not g.is_contiguous()):
+            st = None
+        g = g.contiguous().view(M, D)
+        cur16 = st.view(M, D) if (st is not None and bf) else None
+        if ctx.chain and cur16 is None:
+            cur16 = p_cast(g, act_dtype)
+        cur32 = None if ctx.chain else g
+        saved = ctx.saved_tensors
+        need_all = ctx.needs_input_grad
+        out = [None] * (nblk * 12)
+        for b in reversed(range(nblk)):
+            P = ctx.params[b * 12:(b + 1) * 12]
+            sl = ctx.slots[b * 12:(b + 1) * 12]
+            need = (True,) + tuple(need_all[8 + b * 12 + i] for i in range(12))
+            gslots = (sl[2], sl[4], sl[8], sl[10])
+            vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
+            cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
+                                                need, cur32, cur16, ctx.chain)
+            for i, (p, gr, slot) in enumerate(zip(P, grads, sl)):
+                if gr is None:
+                    continue
+                owner = slot.owner() if slot is not None else None
+                if owner is not None and gr.data_ptr() == slot.ptr and p.grad is None and slot.single_use():
+                    # zero-copy gradient inside its all-reduce bucket: publish it now (autograd gets None for it)
+                    p.grad = gr
+                    owner._on_grad(p)
+                else:
+                    out[b * 12 + i] = gr
+        if ctx.chain:
+            dx = p_cast(cur16, torch.float32)
+        else:
+            dx = cur32
+        dx = dx.view(B, T, D)
+        if cur16 is not None:
+            dx._segclip_bf16 = cur16.view(B, T, D)
+        return (dx, None, None, None, None, None, None, None) + tuple(out)
+
+
+def res_stack(x, blocks_params, n_head, causal, act, eps, act_dtype, klen=None):
+    """Run consecutive residual blocks (each a 12-tuple of parameters in ResBlockFn order) as one ResStackFn node."""
+    from . import config as _cfg
+    flat = [p for P in blocks_params for p in P]
+    return ResStackFn.apply(x, n_head, causal, act, eps, act_dtype, klen, bool(_cfg.bf16_resgrad), *flat)
 
 
 class CrossAttnFn(Function):

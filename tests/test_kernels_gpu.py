@@ -476,3 +476,52 @@ def test_weight_shadow_registry_and_multi_cast():
     assert ops.refresh_weight_shadows(force=False) == 1
     assert torch.equal(copies[1], ws[1].detach().to(BF))
     assert ops.wcast(ws[2], F32).dtype == F32  # the f32 mode never touches the copies
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("causal", [False, True])
+def test_res_stack_matches_block_by_block(dtype, causal):
+    """ops.ResStackFn (N blocks as one autograd node) against N ops.ResBlockFn nodes: identical kernels in identical
+    order, so outputs and every gradient are bit-equal with the fp32 residual gradient; with the bf16 residual-gradient
+    chain (bf16 mode) the gradients stay within bf16 rounding of it."""
+    import segclip_amd
+    B, T, D, H, nblk = 3, 40, 128, 4, 3
+    torch.manual_seed(7)
+    blocks = []
+    for _ in range(nblk):
+        P = [torch.ones(D) + 0.1 * torch.randn(D), 0.1 * torch.randn(D), torch.randn(3 * D, D) * D ** -0.5,
+             0.1 * torch.randn(3 * D), torch.randn(D, D) * D ** -0.5, 0.1 * torch.randn(D),
+             torch.ones(D) + 0.1 * torch.randn(D), 0.1 * torch.randn(D), torch.randn(4 * D, D) * D ** -0.5,
+             0.1 * torch.randn(4 * D), torch.randn(D, 4 * D) * (4 * D) ** -0.5, 0.1 * torch.randn(D)]
+        blocks.append([p.to(DEV).requires_grad_() for p in P])
+    x0 = torch.randn(B, T, D, device=DEV)
+    gout = torch.randn(B, T, D, device=DEV)
+
+    def run(mode):
+        for P in blocks:
+            for p in P:
+                p.grad = None
+        x = x0.clone().requires_grad_()
+        if mode == "blocks":
+            y = x
+            for P in blocks:
+                y = ops.ResBlockFn.apply(y, *P, H, causal, ops.ACT_QUICK_GELU, 1e-5, dtype)
+        else:
+            with segclip_amd.config.scope(bf16_resgrad=(mode == "chain")):
+                y = ops.res_stack(x, blocks, H, causal, ops.ACT_QUICK_GELU, 1e-5, dtype)
+        y.backward(gout)
+        return y.detach(), x.grad.clone(), [[p.grad.clone() for p in P] for P in blocks]
+
+    y0, dx0, g0 = run("blocks")
+    y1, dx1, g1 = run("stack")
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for a, b in zip(g0, g1):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    if dtype == BF:
+        y2, dx2, g2 = run("chain")
+        assert torch.equal(y0, y2)
+        pairs = [(dx0, dx2)] + [(u, v) for a, b in zip(g0, g2) for u, v in zip(a, b)]
+        for u, v in pairs:
+            rel = float((u - v).norm() / u.norm().clamp_min(1e-12))
+            assert rel <= 2e-2, rel
