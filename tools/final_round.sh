@@ -17,7 +17,12 @@ timeout 300 python tools/bench_hbm.py 2>&1 | grep -v "$F" > $OUT/hbm_kernels.txt
 timeout 300 python tools/bench_gemm.py 2>&1 | grep -v "$F" > $OUT/gemm_shapes.txt
 timeout 300 python tools/bench_gemm.py 19712 text 2>&1 | grep -v "$F" >> $OUT/gemm_shapes.txt
 timeout 200 python tools/bench_attn.py 2>&1 | grep -v "$F" > $OUT/attn.txt
-for a in 0 1 2 3 4; do SEGCLIP_P8_ABL=$a timeout 200 python tools/bench_gemm_abl.py 2>&1 | grep "ABL="; done > $OUT/gemm_ablation.txt
+# main-loop ablations: only meaningful with a library built with `build.sh -DSEGCLIP_P8_ABLATIONS`
+if nm -D segclip_amd/libsegclip_hip.so | grep -q segclip_p8_launch_abl1; then
+  for a in 0 1 2 3 4; do SEGCLIP_P8_ABL=$a timeout 200 python tools/bench_gemm_abl.py 2>&1 | grep "ABL="; done > $OUT/gemm_ablation.txt
+else
+  echo "library built without -DSEGCLIP_P8_ABLATIONS: ablations skipped" > $OUT/gemm_ablation.txt
+fi
 timeout 300 python tools/bench_train_tail.py 2>&1 | grep -v "$F" > $OUT/train_tail.txt
 timeout 300 python tools/debug/gradsync_cost.py 2>&1 | grep "ms/step" > $OUT/gradsync_cost.txt
 bash tools/pmc_attn.sh $OUT/pmc_attn > $OUT/pmc_attn.log 2>&1
