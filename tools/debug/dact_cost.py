@@ -13,6 +13,7 @@ x = torch.randn(M, D, device="cuda").to(BF); w1 = (torch.randn(F, D, device="cud
 fl = 2.0 * M * D * F
 for name, fn in (("dgrad plain            ", lambda: ops.p_dgrad(dy, w2, BF)),
                  ("dgrad * act'(u)        ", lambda: ops.p_dgrad(dy, w2, BF, aux=u, act=ops.ACT_QUICK_GELU)),
+                 ("dgrad * 1 (aux loaded) ", lambda: ops.p_dgrad(dy, w2, BF, aux=u, act=ops.ACT_NONE)),
                  ("dgrad * act'(u) +colsum", lambda: ops.p_dgrad(dy, w2, BF, aux=u, act=ops.ACT_QUICK_GELU, want_colsum=True)),
                  ("fwd bias               ", lambda: ops.p_linear(x, w1, b1)),
                  ("fwd bias gelu          ", lambda: ops.p_linear(x, w1, b1, act=ops.ACT_QUICK_GELU)),
