@@ -55,7 +55,7 @@ def parse():
                     help="N>1 gradient exchange: segclip_amd.dist.GradSync (default) or torch DDP (comparison only)")
     ap.add_argument("--attn-fp8", default="auto", choices=["auto", "on", "off"],
                     help="e4m3 MFMA for QK^T / PV in the self-attention forward (auto: on for --spec vitl14_336 = configs[4])")
-    ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format")
+    ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format (auto = fp32, what the reference DDP exchanges; bf16 is an opt-in)")
     return ap.parse_args()
 
 
@@ -220,7 +220,7 @@ def main():
         # gradient all-reduce of the data-parallel step (the reference: DDP, main_task_align.py:251-252): flat aligned
         # buckets filled directly by the weight-gradient kernels, exchanged on a communication stream as they complete
         from segclip_amd.dist import GradSync
-        net = GradSync(model, compress={"auto": "auto", "bf16": True, "fp32": False}[a.wire])
+        net = GradSync(model, compress={"auto": False, "bf16": True, "fp32": False}[a.wire])  # fp32 wire unless asked
     elif multi:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                         find_unused_parameters=True, bucket_cap_mb=64, static_graph=True)

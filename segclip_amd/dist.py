@@ -19,8 +19,13 @@ broadcast), and are always launched in index order, so every rank issues the sam
 Semantics = DDP's: gradients are averaged over ranks after every backward (also under gradient
 accumulation, where the bucket holds previous-average + new-local, as with DDP); parameters that
 receive no gradient keep `grad is None` (find_unused_parameters=True behaviour).
-Wire format: bf16 when the model runs in bf16 mode (halves the xGMI bytes:
-ViT-B/16 627 MB -> 313 MB per step), fp32 otherwise or with compress=False.
+Like DDP's constructor, GradSync broadcasts rank 0's parameters and buffers to every rank when it wraps the
+module, so ranks that were built with different seeds / partially loaded checkpoints start from one state.
+Wire format: fp32 by default (what the reference's DDP exchanges).  compress=True (or "auto" in bf16 mode) is an
+explicit opt-in to a bf16 wire (halves the xGMI bytes: ViT-B/16 627 MB -> 313 MB per
+step): every gradient is then rounded to 8 mantissa bits before the cross-rank sum, so results depend on the world
+size beyond fp32 rounding; a bucket that holds accumulated gradients (no_sync micro-steps) is always
+exchanged in fp32 so that the already-averaged part is not rounded again.
 """
 import os
 import weakref
@@ -77,7 +82,7 @@ class _Slot:
 
 
 class GradSync(nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=64, compress="auto"):
+    def __init__(self, module, process_group=None, bucket_mb=64, compress=False, broadcast_init=True):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -97,7 +102,36 @@ class GradSync(nn.Module):
         self._comm = None
         self._pass_id = 0
         self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0}
+        self._accumulated = False    # a no_sync() backward left local gradients in the buckets
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
+        if broadcast_init and self.world > 1:
+            self.broadcast_state()
+
+    def broadcast_state(self, src=0):
+        """DDP-constructor semantics: every rank takes rank `src`'s parameters and buffers (ONE coalesced broadcast per
+        dtype/device).  bf16 weight shadows of the old values are dropped."""
+        gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
+        tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
+        groups = {}
+        for t in tensors:
+            groups.setdefault((t.dtype, t.device), []).append(t)
+        for (dtype, dev), ts in groups.items():
+            if dtype == torch.bool:
+                for t in ts:
+                    u = t.to(torch.uint8)
+                    dist.broadcast(u, src=gsrc, group=self.group)
+                    t.copy_(u.bool())
+                continue
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=gsrc, group=self.group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))
+                off += n
+        for p in self.module.parameters():
+            if hasattr(p, "_segclip_shadow"):
+                del p._segclip_shadow
 
     def remove(self):
         """Detach from the module: drop the hooks and the parameters' slot references (gradients stay where they are)."""
@@ -122,6 +156,7 @@ class GradSync(nn.Module):
         class _Ctx:
             def __enter__(self):
                 self.prev, outer._sync_enabled = outer._sync_enabled, False
+                outer._accumulated = True
 
             def __exit__(self, *exc):
                 outer._sync_enabled = self.prev
@@ -196,7 +231,7 @@ class GradSync(nn.Module):
             for st in self._bstreams[b]:          # every stream that produced a gradient of this bucket
                 self._comm.wait_stream(st)
             with torch.cuda.stream(self._comm):
-                if self._use_bf16(flat):
+                if self._use_bf16(flat) and not self._accumulated:
                     wire = self._wire[b]
                     ops.p_cast_into(flat, wire)
                     dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=self.group)
@@ -230,11 +265,21 @@ class GradSync(nn.Module):
                             self._slots[i].view().zero_()
                             p.grad = self._slots[i].view()
                 self._exchange(b)
+            if dist.is_initialized() and self.world > 1:
+                # the number of late exchanges must be the same on every rank (data-dependent use): agree first, raise
+                # everywhere instead of hanging in mismatched collectives
+                dev = self._flat[0].device if self._flat else torch.device("cpu")
+                n = torch.tensor([len(self._late), -len(self._late)], dtype=torch.int64, device=dev)
+                dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+                if int(n[0]) != -int(n[1]):
+                    raise RuntimeError("GradSync: ranks disagree on the parameters that received late gradients")
             for p in self._late:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
                 p.grad.div_(self.world)
         if self._comm is not None and self._launched:
             torch.cuda.current_stream(self._flat[0].device).wait_stream(self._comm)
+        if self._sync_enabled:
+            self._accumulated = False
         self._reset_pass()
 
     def _reset_pass(self):
@@ -253,8 +298,12 @@ class GradSync(nn.Module):
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
                                        group=self.group)
             order = box[0]
-            mine = set(self._first_order)
-            if set(order) != mine:
+            # the verdict is taken collectively, so that EVERY rank raises (rank 0 always agrees with its own order and
+            # would otherwise walk into the bucket all-reduces alone: a hang until the RCCL timeout)
+            dev = self._params[order[0]].device if order else torch.device("cpu")
+            bad = torch.tensor([int(set(order) != set(self._first_order))], dtype=torch.int32, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            if int(bad):
                 raise RuntimeError("GradSync: ranks disagree on the set of parameters that receive gradients")
         buckets, cur, cur_elems = [], [], 0
         for i in order:

@@ -523,7 +523,7 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
 N_SAVED = 19
 
 
-def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain):
+def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False):
     """Hand-scheduled backward of one block.  g: fp32 (M, D) gradient of the block output or None; g16: its bf16 copy or
     None.  need[i]: gradient wanted for forward input i (0 = x, 1..12 = the parameters in forward order).
     chain=False: fp32 residual gradient in and out (plus the bf16 copy the LayerNorm backward emits for free).
@@ -545,9 +545,9 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain):
     rdt = act_dtype if chain else torch.float32
     # The weight gradients do not feed the data-gradient chain: optionally (config.overlap_wgrad) they are enqueued
     # on a second HIP stream.
-    from . import config as _cfg
+    # (the switch is captured at FORWARD time: backward runs on the autograd thread, after config.scope() has exited)
     main = torch.cuda.current_stream()
-    side = _wgrad_stream() if _cfg.overlap_wgrad else None
+    side = _wgrad_stream() if overlap_wgrad else None
     sq, so, sf, sp = gslots  # weight gradients land directly in their all-reduce bucket (segclip_amd/dist.py)
     F4 = wfc_c.shape[0]
     s_ln1w, s_ln1b, s_bqkv, s_bo, s_ln2w, s_ln2b, s_bfc, s_bpr = vslots   # ... and so do the 8 vector gradients
@@ -616,6 +616,8 @@ class ResBlockFn(Function):
         ctx.save_for_backward(*saved)
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
         ctx.klen = klen
+        from . import config as _cfg
+        ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
         ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
         ctx.vslots = tuple(_slot_of(w) for w in (ln1w, ln1b, bqkv, bo, ln2w, ln2b, bfc, bpr))
         return xo.view(B, T, D)
@@ -630,7 +632,7 @@ class ResBlockFn(Function):
         g = g.contiguous().view(M, D)
         g16 = st.view(M, D) if (st is not None and act_dtype == torch.bfloat16) else None
         dx, dx16, grads = _resblock_bwd(ctx.saved_tensors, ctx.cfg, ctx.klen, ctx.gslots, ctx.vslots,
-                                        ctx.needs_input_grad, g, g16, False)
+                                        ctx.needs_input_grad, g, g16, False, ctx.overlap_wgrad)
         dx = dx.view(B, T, D)
         if dx16 is not None:
             dx._segclip_bf16 = dx16.view(B, T, D)
@@ -661,6 +663,8 @@ class ResStackFn(Function):
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
         ctx.klen, ctx.nblk = klen, nblk
         ctx.chain = bool(chain) and act_dtype == torch.bfloat16
+        from . import config as _cfg
+        ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
         ctx.params = params
         ctx.slots = tuple(_slot_of(w) for w in params)
         return cur.view(B, T, D)
@@ -688,7 +692,7 @@ class ResStackFn(Function):
             gslots = (sl[2], sl[4], sl[8], sl[10])
             vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
             cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
-                                                need, cur32, cur16, ctx.chain)
+                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad)
             for i, (p, gr, slot) in enumerate(zip(P, grads, sl)):
                 if gr is None:
                     continue
@@ -984,8 +988,24 @@ class CrossEntropyLabelsFn(Function):
 
 def prefix_mask_lengths(attention_mask):
     """(B, L) 0/1 attention mask of END-PADDED captions (the dataloader contract, dataloaders/dataloader_cc_retrieval.py:
-    valid tokens first) -> int32 (B,) number of valid keys, the form the attention kernels take the key-padding mask in."""
-    return attention_mask.reshape(attention_mask.shape[0], -1).to(torch.int32).sum(dim=1, dtype=torch.int32).contiguous()
+    valid tokens first) -> int32 (B,) number of valid keys, the form the attention kernels take the key-padding mask in.
+    The prefix form (no interior zeros, no left padding, at least one valid key per row - a row without keys has
+    lse = -inf) is VALIDATED on the first call of the process and on every call with SEGCLIP_CHECK_MASKS=1 (one host
+    synchronisation); other masks raise instead of silently attending to the wrong keys."""
+    m = attention_mask.reshape(attention_mask.shape[0], -1)
+    global _MASK_CHECKED
+    if not _MASK_CHECKED or _CHECK_MASKS:
+        _MASK_CHECKED = True
+        mi = m.to(torch.int32)
+        ok = bool(((mi[:, 1:] <= mi[:, :-1]).all() & (mi[:, 0] >= 1).all() & ((mi == 0) | (mi == 1)).all()).item())
+        if not ok:
+            raise NotImplementedError("attention_mask must be a 0/1 PREFIX mask with >= 1 valid token per row "
+                                      "(end-padded captions); interior zeros / left padding are not supported")
+    return m.to(torch.int32).sum(dim=1, dtype=torch.int32).contiguous()
+
+
+_MASK_CHECKED = False
+_CHECK_MASKS = bool(int(__import__("os").environ.get("SEGCLIP_CHECK_MASKS", "0")))
 
 
 class SuperpixelKLFn(Function):

@@ -124,3 +124,55 @@ def test_gradsync_without_process_group_is_a_plain_wrapper():
         assert (p.grad is None) == (q.grad is None)
         if q.grad is not None:
             assert torch.equal(p.grad, q.grad) and p.grad.data_ptr() % 64 == 0
+
+
+class Toy2(Toy):
+    """Toy with a buffer; rank r perturbs its weights before wrapping (per-rank seed / partial checkpoint load)."""
+
+    def __init__(self, rank):
+        super().__init__()
+        self.register_buffer("running", torch.full((3,), float(rank)))
+        with torch.no_grad():
+            self.a.add_(0.5 * rank)
+            self.scale.fill_(1.0 + rank)
+
+
+def _worker_init(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segclip_amd.dist import GradSync
+    m = Toy2(rank)
+    m.a._segclip_shadow = ["stale", -1]          # a bf16 shadow of the pre-broadcast value must not survive
+    net = GradSync(m)
+    ref = Toy2(0)
+    for (n, p), (_, q) in zip(net.module.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), (rank, n)     # DDP-constructor semantics: rank 0's state everywhere
+    assert torch.equal(net.module.running, ref.running)
+    assert not hasattr(net.module.a, "_segclip_shadow")
+    # broadcast_init=False keeps the local state (the caller's responsibility, e.g. identical seeds)
+    keep = GradSync(Toy2(rank), broadcast_init=False)
+    assert float(keep.module.scale) == 1.0 + rank
+    keep.remove()
+    # ranks that disagree on which parameters receive gradients: EVERY rank raises (no rank walks into a collective alone)
+    class Branchy(Toy):
+        def forward(self, x):
+            y = super().forward(x)
+            return y + (self.unused.sum() if dist.get_rank() == 1 else 0.0)
+    bad = GradSync(Branchy())
+    x = torch.randn(6, 3, generator=torch.Generator().manual_seed(rank))
+    raised = False
+    try:
+        bad(x).backward()
+    except RuntimeError as e:
+        raised = "disagree" in str(e)
+    assert raised, rank
+    torch.save(True, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_gradsync_broadcasts_initial_state_and_raises_on_every_rank(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_init, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert all(os.path.exists(f"{out}.{r}") for r in range(2))
