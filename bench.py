@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs (HBM bytes of the GEMM)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N>1 code path (RCCL group, GradSync, barriers) even with one rank: single-GPU check of it")
     ap.add_argument("--grad-sync", default="segclip", choices=["segclip", "ddp"],
@@ -178,6 +179,107 @@ def respawn(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def child_argv(a, steps, warmup):
+    """bench.py command line of the same per-GPU workload on ONE GPU, without the roofline / CPU-baseline legs."""
+    argv = [os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch", str(a.batch),
+            "--spec", a.spec, "--dtype", a.dtype, "--attn-fp8", a.attn_fp8, "--no-roofline", "--no-cpu-baseline"]
+    if a.full_loss:
+        argv.append("--full-loss")
+    return argv
+
+
+PEAK_HBM_GBS = 8000.0
+
+
+def roofline_block(a, step, pairs_per_gpu, world):
+    """Roofline of the kernel classes that carry the step, from KERNEL time: this command's per-GPU workload is run again
+    for a few steps as a child under `rocprofv3 --kernel-trace --stats` (and under two counters-only --pmc passes for the
+    HBM bytes of the dominant kernel); the algorithmic flops / bytes of each class are counted by the op layer during one
+    pass of the parent.  The towers run on two streams, so class times may overlap each other (their sum exceeds the step
+    time); a class time is the sum of its kernels' own durations, exactly what `rocprofv3 --stats` prints."""
+    from tools import rocprof_roofline as rr
+    ops._OpCount.start()
+    step()
+    torch.cuda.synchronize()
+    work = {}
+    for kind, fl, nb in ops._OpCount.stop():
+        w = work.setdefault(kind, [0, 0.0, 0.0])
+        w[0] += 1; w[1] += fl; w[2] += nb
+    step_frac = (round(pairs_per_gpu * GF_PER_PAIR[(a.spec, a.full_loss)] / 1e3 / PEAK_BF16_TF, 4)
+                 if (a.spec, a.full_loss) in GF_PER_PAIR else None)
+    ksteps, kwarm = 4, 2
+    keep = os.environ.get("SEGCLIP_BENCH_PROFILE_DIR")   # tools/profile_round.sh keeps the database and the summary
+    try:
+        m = rr.measure(child_argv(a, ksteps, kwarm), ksteps + kwarm,
+                       pmc_argv=None if a.no_traffic else child_argv(a, 1, 1), keep_dir=keep, timeout=600)
+    except Exception as e:
+        return roofline_fallback(a, step, step_frac, f"rocprofv3 child not usable here ({type(e).__name__}: {str(e)[:200]})")
+    cl = m["classes"]
+    if keep:
+        with open(os.path.join(keep, "kernel_stats.txt"), "w") as f:
+            f.write(rr.format_table(m["table"], ksteps + kwarm,
+                                    header=f"# rocprofv3 --kernel-trace --stats -- python {' '.join(child_argv(a, ksteps, kwarm)[1:])}\n"
+                                           f"# (the child run bench.py's roofline block is computed from)"))
+
+    def mfma(kind, cls):
+        if kind not in work or cls not in cl or cl[cls]["time_per_step_ms"] <= 0:
+            return None
+        n, fl, nb = work[kind]
+        t = cl[cls]["time_per_step_ms"] * 1e-3
+        return {"time_per_step_ms": cl[cls]["time_per_step_ms"], "launches_per_step": cl[cls]["launches_per_step"],
+                "avg_launch_us": cl[cls]["avg_launch_us"], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(fl / t / 1e12 / PEAK_BF16_TF, 4), "algorithmic_gbytes_per_s": round(nb / t / 1e9, 1)}
+
+    def hbm(kind, cls):
+        if kind not in work or cls not in cl or cl[cls]["time_per_step_ms"] <= 0:
+            return None
+        n, fl, nb = work[kind]
+        t = cl[cls]["time_per_step_ms"] * 1e-3
+        return {"time_per_step_ms": cl[cls]["time_per_step_ms"], "launches_per_step": cl[cls]["launches_per_step"],
+                "avg_launch_us": cl[cls]["avg_launch_us"], "bound": "hbm", "achieved": round(nb / t / 1e9, 1), "unit": "GB/s",
+                "frac": round(nb / t / 1e9 / PEAK_HBM_GBS, 4)}
+
+    g = mfma("gemm_bf16", "gemm_bf16")
+    if g is None:
+        return roofline_fallback(a, step, step_frac, "no bf16 GEMM dispatch in the rocprofv3 trace")
+    n, fl, nb = work["gemm_bf16"]
+    classes = {"gemm_bf16": g, "attention_fwd": mfma("attn_fwd", "attn_fwd"), "attention_bwd": mfma("attn_bwd", "attn_bwd"),
+               "layernorm_bwd": hbm("ln_bwd", "ln_bwd"), "layernorm_fwd": hbm("ln_fwd", "ln_fwd")}
+    for extra in ("splitk_reduce", "row_reductions", "gemm_f32", "other"):
+        if extra in cl:
+            classes[extra] = {"time_per_step_ms": cl[extra]["time_per_step_ms"], "launches_per_step": cl[extra]["launches_per_step"]}
+    tr = m["traffic"]
+    return {"bound": "mfma", "kernel": "gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback), all launches of a step",
+            "achieved": g["achieved"], "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": g["frac"],
+            "avg_launch_us": g["avg_launch_us"], "launches_per_step": g["launches_per_step"],
+            "time_per_step_ms": g["time_per_step_ms"],
+            "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(nb / n),
+            "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_detail": tr,
+            "source": f"kernel durations of a rocprofv3 --kernel-trace --stats child run of this workload on one GPU ({ksteps + kwarm} model "
+                      "passes, text tower concurrent on its second stream as in the timed region); flops / bytes counted by the op layer",
+            "two_stream_note": "class times are sums of kernel durations on two concurrent streams: they may add up to more than ms_per_step",
+            "all_kernels_ms_per_step": round(sum(v["time_per_step_ms"] for v in cl.values()), 3),
+            "classes": classes, "step_frac": step_frac, "notes": m["notes"]}
+
+
+def roofline_fallback(a, step, step_frac, why):
+    """HIP-event timing of every bf16 GEMM launch with the towers SERIALISED (one stream: an event interval is then the
+    kernel's own time plus its dispatch gap) - used only where rocprofv3 cannot be started."""
+    segclip_amd.config.overlap_towers = False
+    step()
+    ops._GemmProfile.start()
+    step()
+    rec = [r for r in ops._GemmProfile.stop() if r[2]]
+    segclip_amd.config.overlap_towers = True
+    tsum, fsum = sum(r[0] for r in rec), sum(r[1] for r in rec)
+    return {"bound": "mfma", "kernel": "bf16 GEMM kernels, all launches of a step", "achieved": round(fsum / tsum / 1e12, 1),
+            "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(fsum / tsum / 1e12 / PEAK_BF16_TF, 4), "traffic": None,
+            "avg_launch_us": round(tsum / len(rec) * 1e6, 1), "launches_per_step": len(rec),
+            "algorithmic_flops_per_launch": round(fsum / len(rec)),
+            "algorithmic_bytes_per_launch": round(sum(r[3] for r in rec) / len(rec)),
+            "source": "FALLBACK: HIP events around serialised launches (towers on one stream); " + why, "step_frac": step_frac}
+
+
 def main():
     a = parse()
     if a.cpu_baseline_worker:
@@ -256,43 +358,8 @@ def main():
     pairs = a.batch * world * a.steps / elapsed
 
     roofline = None
-    if not a.no_roofline and a.dtype == "bf16":
-        # dominant kernel = the bf16 GEMM (all layouts): per-launch HIP-event timing on the launch stream, taken in the
-        # SAME condition as the timed region (text tower concurrent on its own stream); a second pass with the towers
-        # serialised gives the isolated-kernel figure for comparison
-        def gemm_pass():
-            step()
-            ops._GemmProfile.start()
-            step()
-            return [r for r in ops._GemmProfile.stop() if r[2]]
-        rec = gemm_pass()
-        segclip_amd.config.overlap_towers = False
-        rec_iso = gemm_pass()
-        segclip_amd.config.overlap_towers = True
-        tsum, fsum = sum(r[0] for r in rec), sum(r[1] for r in rec)
-        tiso, fiso = sum(r[0] for r in rec_iso), sum(r[1] for r in rec_iso)
-        big = [r for r in rec if r[1] >= 1e11]
-        # HBM bytes per GEMM launch: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, FETCH doubled per the
-        # gfx950 note of MI355X_MICROARCH.md) of this same command, committed under profiles/ - NOT measured in this run
-        traffic, tsrc = None, None
-        tf = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
-        if a.batch == 256 and a.spec == "vitb16" and not a.full_loss and os.path.exists(tf):
-            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
-            tsrc = "profiles/r02_gemm_traffic.json (rocprofv3 --pmc passes of this command; not re-measured in this run)"
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback)",
-                    "achieved": round(fsum / tsum / 1e12, 1),
-                    "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(fsum / tsum / 1e12 / PEAK_BF16_TF, 4),
-                    "condition": "as in the timed region (text tower concurrent on a second stream)",
-                    "achieved_isolated": round(fiso / tiso / 1e12, 1),
-                    "traffic": traffic, "traffic_source": tsrc,
-                    "algorithmic_flops_per_launch": round(fsum / len(rec)),
-                    "algorithmic_bytes_per_launch": round(sum(r[3] for r in rec) / len(rec)),
-                    "launches_per_step": len(rec),
-                    "avg_launch_us": round(tsum / len(rec) * 1e6, 1),
-                    "gemm_time_per_step_ms": round(tsum * 1e3, 2),
-                    "large_gemm_tflops": round(sum(r[1] for r in big) / max(sum(r[0] for r in big), 1e-9) / 1e12, 1),
-                    "step_frac": (round(pairs / world * GF_PER_PAIR[(a.spec, a.full_loss)] / 1e3 / PEAK_BF16_TF, 4)
-                                  if (a.spec, a.full_loss) in GF_PER_PAIR else None)}
+    if not a.no_roofline and a.dtype == "bf16" and rank == 0:
+        roofline = roofline_block(a, step, pairs / world, world)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()

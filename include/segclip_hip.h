@@ -45,6 +45,8 @@ const char* segclip_last_error_string(void);
  * GEMM with fused epilogue.   C[z](m,n) = epi( alpha * sum_k A[z](m,k) * B[z](n,k) )
  *   epi(v): v += bias[n];  if act: (aux ? aux(m,n) = v : 0), v = act(v);   v += residual(m,n)
  *   mul_dact: v = v * act'(aux(m,n))   (aux is an INPUT: the saved pre-activation; bias/residual unused)
+ *   aux_kind 1: aux holds act'(pre-activation) instead of the pre-activation - the forward epilogue stores the
+ *               derivative (its exponential is already computed there) and mul_dact multiplies by aux as it is
  * Replaces nn.Linear / MHA in-proj / out-proj / the einsum + Conv1d contractions:
  *   modules/module_seg_vit.py:166-172,189,266-269,304,309 ; modules/module_clip_ttransformer.py:24-30 ;
  *   modules/module_clip.py:91-94,131-134 ; modules/modeling.py:356-357 and their autograd backward
@@ -72,7 +74,7 @@ typedef struct segclip_gemm_desc {
   int32_t act;
   int32_t mul_dact;
   float alpha;
-  int32_t reserved;
+  int32_t aux_kind; /* 0: aux = pre-activation; 1: aux = act'(pre-activation) */
   void* ws;         /* optional split-K scratch (bf16 path, plain epilogue only); NULL = no split-K */
   int64_t ws_bytes; /* size of ws; segclip_gemm_ws_bytes(d) is the amount that enables split-K */
   float* colsum;    /* optional [N] fp32: column sums of the stored C (bias gradient fused into the epilogue).

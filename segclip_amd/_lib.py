@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("bsA1", i64), ("bsA2", i64), ("bsB1", i64), ("bsB2", i64), ("bsC1", i64), ("bsC2", i64),
                 ("bsR1", i64), ("bsR2", i64),
                 ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("r_dtype", i32),
-                ("act", i32), ("mul_dact", i32), ("alpha", f32), ("reserved", i32),
+                ("act", i32), ("mul_dact", i32), ("alpha", f32), ("aux_kind", i32),
                 ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp)]
 
 

@@ -31,6 +31,8 @@ extern "C" int segclip_gemm(const segclip_gemm_desc* d, void* stream) {
   if (d->M == 0 || d->N == 0) return 0;
   SEGCLIP_REQUIRE(d->A && d->B && d->C, "gemm: null operand");
   SEGCLIP_REQUIRE(!d->mul_dact || d->aux, "gemm: mul_dact needs aux");
+  SEGCLIP_REQUIRE(d->aux_kind == 0 || (d->aux_kind == 1 && d->act == SEGCLIP_ACT_QUICK_GELU),
+                  "gemm: aux_kind 1 (aux = act'(pre-activation)) is implemented for QuickGELU only");
   if (d->a_dtype == SEGCLIP_F32 && d->b_dtype == SEGCLIP_F32) {
     SEGCLIP_REQUIRE(d->c_dtype == SEGCLIP_F32 && (!d->residual || d->r_dtype == SEGCLIP_F32),
                     "gemm f32: output / residual must be f32");

@@ -439,7 +439,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.nb2 = d->nb2 > 0 ? d->nb2 : 1;
   g.bsA1 = d->bsA1; g.bsA2 = d->bsA2; g.bsB1 = d->bsB1; g.bsB2 = d->bsB2; g.bsC1 = d->bsC1; g.bsC2 = d->bsC2;
   g.bsR1 = d->bsR1; g.bsR2 = d->bsR2;
-  g.c_dtype = d->c_dtype; g.r_dtype = d->r_dtype; g.act = d->act; g.mul_dact = d->mul_dact; g.alpha = d->alpha;
+  g.c_dtype = d->c_dtype; g.r_dtype = d->r_dtype; g.act = d->act; g.mul_dact = d->mul_dact; g.aux_kind = d->aux_kind; g.alpha = d->alpha;
   g.nbx = (int)cdiv(d->N, BN); g.nby = (int)cdiv(d->M, BM);
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * g.nb2;
   SEGCLIP_REQUIRE(nb <= 65535, "gemm_bf16: batch too large (%lld)", (long long)nb);
@@ -449,6 +449,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   if (g.splits > 1) g.splits = (int)cdiv(d->K, g.kper);
   g.slab = (float*)d->ws;
   g.vec_epi = 0;
+  g.touch = 0;
   g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
   const bool fast = aligned16(d);

@@ -15,11 +15,29 @@ struct Args {
   int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
   float* colsum_part;  // optional [M/64][N] fp32 partial column sums of the stored output (LDS epilogue only)
   int vec_epi;  // host-checked: every C / aux / residual / bias access of a full tile may be a 16-byte vector
+  int touch;    // 8-phase kernel: pre-touch the epilogue's side tile (SEGCLIP_P8_TOUCH, default on)
+  int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u)
 };
 
 
 // ---- epilogue -------------------------------------------------------------------------------
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
+
+// forward activation epilogue: v (pre-activation) -> act(v); *side = what is kept for the backward: u, or act'(u) when
+// aux_kind == 1 (QuickGELU only - segclip_gemm rejects aux_kind 1 with any other activation; keeping the erf-GELU
+// derivative out of here also keeps the unrolled epilogues below the pragma-unroll size threshold)
+__device__ __forceinline__ float act_with_side(int act, int aux_kind, float v, float* side) {
+  if (act == SEGCLIP_ACT_QUICK_GELU) {
+    const float sg = sigmoid1702(v);
+    *side = aux_kind ? sg * (1.0f + 1.702f * v * (1.0f - sg)) : v;
+    return v * sg;
+  }
+  *side = v;
+  return apply_act(act, v);
+}
+__device__ __forceinline__ float dact_from_side(int act, int aux_kind, float side) {
+  return aux_kind ? side : apply_act_grad(act, side);
+}
 
 template <typename CT> __device__ __forceinline__ float ldc_(const void* p, int64_t o);
 template <> __device__ __forceinline__ float ldc_<bf16_t>(const void* p, int64_t o) { return bf2f(((const bf16_t*)p)[o]); }
@@ -29,17 +47,16 @@ template <> __device__ __forceinline__ float ldc_<float>(const void* p, int64_t 
 // pairs after a lane^1 exchange: 4-byte stores instead of 2-byte ones).
 // jstride: distance between the two 32-column MFMA tiles of the sub-tile (32: adjacent; 128: the 8-phase kernel, whose
 // waves own one 32-column strip in each 128-column half of the tile)
-template <typename CT, int MODE, bool FULL>
-__device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm, int wn,
-                                         int lane, int64_t coff, int64_t roff, int jstride = 32) {
+// (the (i, j) MFMA tile is a template parameter: with the four tiles in `#pragma unroll` loops the unrolled size can
+// exceed the pragma-unroll threshold, the loops stay rolled and the accumulators are indexed at run time -> scratch)
+template <typename CT, int MODE, bool FULL, int i, int j>
+__device__ __forceinline__ void epilogue_tile(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm,
+                                              int wn, int lane, int64_t coff, int64_t roff, int jstride) {
   const int li = lane & 31, lk = lane >> 5;
   constexpr bool PAIR = FULL && sizeof(CT) == 2;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    {
       const int64_t n = n0 + wn * 64 + j * jstride + li;
-      if (!FULL && n >= g.N) continue;
+      if (!FULL && n >= g.N) return;
       const float bv = (MODE != EPI_DACT && g.bias) ? g.bias[n] : 0.f;
       float val[16], pre[16];
 #pragma unroll
@@ -49,10 +66,10 @@ __device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2
         pre[r] = 0.f;
         if (FULL || m < g.M) {
           if (MODE == EPI_DACT) {
-            v *= apply_act_grad(g.act, ldc_<CT>(g.aux, coff + m * g.ldaux + n));
+            v *= dact_from_side(g.act, g.aux_kind, ldc_<CT>(g.aux, coff + m * g.ldaux + n));
           } else {
             v += bv;
-            if (MODE == EPI_ACT) { pre[r] = v; v = apply_act(g.act, v); }
+            if (MODE == EPI_ACT) v = act_with_side(g.act, g.aux_kind, v, &pre[r]);
             if (g.residual) {
               const int64_t o = roff + m * g.ldr + n;
               v += g.r_dtype == SEGCLIP_BF16 ? bf2f(((const bf16_t*)g.residual)[o]) : ((const float*)g.residual)[o];
@@ -91,6 +108,15 @@ __device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2
     }
 }
 
+template <typename CT, int MODE, bool FULL>
+__device__ __forceinline__ void epilogue(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm, int wn,
+                                         int lane, int64_t coff, int64_t roff, int jstride = 32) {
+  epilogue_tile<CT, MODE, FULL, 0, 0>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
+  epilogue_tile<CT, MODE, FULL, 0, 1>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
+  epilogue_tile<CT, MODE, FULL, 1, 0>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
+  epilogue_tile<CT, MODE, FULL, 1, 1>(g, acc, m0, n0, wm, wn, lane, coff, roff, jstride);
+}
+
 template <typename CT, bool FULL>
 __device__ __forceinline__ void epilogue_mode(const Args& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0, int wm,
                                               int wn, int lane, int64_t coff, int64_t roff, int jstride = 32) {
@@ -114,24 +140,114 @@ __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
 }
 
 // NSPLIT > 0: the sub-tile's local columns 0-31 / 32-63 live at global columns nw + 0..31 / nw + NSPLIT + 0..31.
-template <typename CT, int MODE, int NSPLIT>
-__device__ __forceinline__ void epilogue_lds_plain(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
-                                                   int64_t nw, int lane, int64_t coff);
+// The epilogue of a sub-tile is three stages, so that a kernel with several sub-tiles per wave can interleave them
+// (gemm_bf16_p8.hip issues the side loads of its second half-tile under the row pass of the first):
+//   epi_side_load : ALL residual / saved-activation loads of the 64x64 sub-tile into <= 64 VGPRs (the operand-fragment
+//                   registers are free by now): one memory round trip per sub-tile.  With batches of 4 rows (the first
+//                   version) an fp32-residual epilogue paid 8 dependent round trips per tile: +26..57 us per launch.
+//   epi_park      : accumulators -> the wave's private LDS patch
+//   epi_rows      : row pass (LDS -> bias / activation / act' / residual -> 16-byte stores, column sums)
+template <typename CT> struct EpiGeom {
+  static constexpr int W = sizeof(CT) == 2 ? 8 : 4;   // columns per lane
+  static constexpr int LPR = 64 / W;                   // lanes per row
+  static constexpr int RPI = 64 / LPR;                 // rows per iteration
+  static constexpr int NIT = 64 / RPI;                 // iterations: 8 (bf16 out) / 16 (fp32 out)
+};
+template <typename CT, int NSPLIT> __device__ __forceinline__ int64_t epi_col(int64_t nw, int cl) {
+  constexpr int W = EpiGeom<CT>::W;
+  return NSPLIT > 0 ? nw + ((cl * W) >> 5) * NSPLIT + ((cl * W) & 31) : nw + cl * W;
+}
 
-template <typename CT, int MODE, int NSPLIT = 0>
-__device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
-                                             int lane, int64_t coff, int64_t roff) {
-  if (MODE != EPI_DACT && !g.residual) {   // nothing to load besides the bias: the rolled, low-register form
-    epilogue_lds_plain<CT, MODE, NSPLIT>(g, acc, t, mw, nw, lane, coff);
-    return;
+// Side registers of a sub-tile: NIT 16-byte words per lane, of the OUTPUT element type (the host routes a residual whose
+// dtype differs from the output's to the per-element epilogue): u32x4 = 8 bf16 (W == 8) or f32x4 (W == 4).
+template <typename CT> struct EpiSideT { typedef u32x4 type; };
+template <> struct EpiSideT<float> { typedef f32x4 type; };
+
+template <typename CT, int MODE, int NSPLIT>
+__device__ __forceinline__ void epi_side_load(const Args& g, typename EpiSideT<CT>::type (&sr)[EpiGeom<CT>::NIT], int64_t mw,
+                                              int64_t nw, int lane, int64_t coff, int64_t roff) {
+  using G = EpiGeom<CT>;
+  typedef typename EpiSideT<CT>::type ST;
+  const int cl = lane % G::LPR, rl = lane / G::LPR;
+  const int64_t n = epi_col<CT, NSPLIT>(nw, cl);
+#pragma unroll
+  for (int it = 0; it < G::NIT; ++it) {
+    const int64_t m = mw + it * G::RPI + rl;
+    if (MODE == EPI_DACT) sr[it] = *reinterpret_cast<const ST*>((const CT*)g.aux + coff + m * g.ldaux + n);
+    else sr[it] = *reinterpret_cast<const ST*>((const CT*)g.residual + roff + m * g.ldr + n);
   }
+}
+template <typename CT> __device__ __forceinline__ void epi_side_get(const typename EpiSideT<CT>::type& w, float* f);
+template <> __device__ __forceinline__ void epi_side_get<bf16_t>(const u32x4& w, float* f) { unpack8(w, f); }
+template <> __device__ __forceinline__ void epi_side_get<float>(const f32x4& w, float* f) { f[0] = w[0]; f[1] = w[1]; f[2] = w[2]; f[3] = w[3]; }
+
+__device__ __forceinline__ void epi_park(const Args& g, const f32x16 (&acc)[2][2], float* t, int lane) {
   const int li = lane & 31, lk = lane >> 5;
-  constexpr int W = sizeof(CT) == 2 ? 8 : 4;      // columns per lane
-  constexpr int LPR = 64 / W;                      // lanes per row
-  constexpr int RPI = 64 / LPR;                    // rows per iteration
-  const int cl = lane % LPR, rl = lane / LPR;
-  const int64_t n = NSPLIT > 0 ? nw + ((cl * W) >> 5) * NSPLIT + ((cl * W) & 31) : nw + cl * W;
-  float bias[W];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
+}
+
+// one row segment: v[W] (LDS values) -> stored output; returns nothing, accumulates csum
+template <typename CT, int MODE>
+__device__ __forceinline__ void epi_finish_row(const Args& g, float (&v)[EpiGeom<CT>::W], const float (&bias)[EpiGeom<CT>::W],
+                                               float (&csum)[EpiGeom<CT>::W], int64_t m, int64_t n, int64_t coff) {
+  constexpr int W = EpiGeom<CT>::W;
+  if (MODE != EPI_DACT) {
+#pragma unroll
+    for (int c = 0; c < W; ++c) v[c] += bias[c];
+  }
+  if (MODE == EPI_ACT) {
+    float sd[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) v[c] = act_with_side(g.act, g.aux_kind, v[c], &sd[c]);
+    if (g.aux) {
+      if (sizeof(CT) == 2) {
+        u32x4 p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = pack2bf(sd[2 * c], sd[2 * c + 1]);
+        __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n));
+      } else {
+        __builtin_nontemporal_store(f32x4{sd[0], sd[1], sd[2], sd[3]},
+                                    reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n));
+      }
+    }
+  }
+}
+template <typename CT>
+__device__ __forceinline__ void epi_store_row(const Args& g, const float (&v)[EpiGeom<CT>::W], int64_t m, int64_t n,
+                                              int64_t coff) {
+  if (sizeof(CT) == 2) {
+    u32x4 p;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
+    // non-temporal: the output is not re-read by this kernel and should not displace the W tiles in L2
+    // (measured -0.4 ms per training step)
+    __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n));
+  } else {
+    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n));
+  }
+}
+template <typename CT>
+__device__ __forceinline__ void epi_colsum(const Args& g, const float (&csum)[EpiGeom<CT>::W], int64_t mw, int64_t n, int rl) {
+  using G = EpiGeom<CT>;
+  if (g.colsum_part) {  // column sums of this wave's 64 rows (bias gradient of the producing Linear)
+#pragma unroll
+    for (int c = 0; c < G::W; ++c) {
+      float x = csum[c];
+#pragma unroll
+      for (int o = G::LPR; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+      if (rl == 0) g.colsum_part[(mw >> 6) * g.N + n + c] = x;
+    }
+  }
+}
+template <typename CT, int MODE>
+__device__ __forceinline__ void epi_load_bias(const Args& g, float (&bias)[EpiGeom<CT>::W], int64_t n) {
+  constexpr int W = EpiGeom<CT>::W;
 #pragma unroll
   for (int c = 0; c < W; ++c) bias[c] = 0.f;
   if (MODE != EPI_DACT && g.bias) {
@@ -141,159 +257,66 @@ __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[
       bias[c] = b[0]; bias[c + 1] = b[1]; bias[c + 2] = b[2]; bias[c + 3] = b[3];
     }
   }
-  // ALL residual / pre-activation loads of the 64x64 sub-tile are issued first (<= 64 VGPRs: the operand-fragment
-  // registers are free by now), so their memory latency is paid once and overlaps the accumulator -> LDS pass.  With
-  // batches of 4 rows (the first version) an fp32-residual epilogue paid 8 dependent round trips per tile: +26..57 us
-  // per launch on the out_proj / c_proj GEMMs.
-  constexpr int NIT = 64 / RPI;
-  constexpr int RW = W / 4;  // 16-byte words per lane for an fp32 side operand
-  f32x4 side_f[NIT][RW];   // fp32 residual
-  u32x4 side_h[NIT];       // bf16 residual (W==8) / bf16 aux
-  u32x2 side_q[NIT];       // bf16 residual when W==4
-  f32x4 aux_f[NIT];        // fp32 aux (W==4)
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int64_t m = mw + it * RPI + rl;
-    if (MODE == EPI_DACT) {
-      if (sizeof(CT) == 2) side_h[it] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.aux + coff + m * g.ldaux + n);
-      else aux_f[it] = *reinterpret_cast<const f32x4*>((const float*)g.aux + coff + m * g.ldaux + n);
-    } else if (g.residual) {
-      const int64_t o = roff + m * g.ldr + n;
-      if (g.r_dtype == SEGCLIP_BF16) {
-        if (W == 8) side_h[it] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.residual + o);
-        else side_q[it] = *reinterpret_cast<const u32x2*>((const bf16_t*)g.residual + o);
-      } else {
-#pragma unroll
-        for (int c = 0; c < RW; ++c) side_f[it][c] = *reinterpret_cast<const f32x4*>((const float*)g.residual + o + 4 * c);
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
-  __builtin_amdgcn_wave_barrier();
-  float csum[W];
-#pragma unroll
-  for (int c = 0; c < W; ++c) csum[c] = 0.f;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    {
-      const int bi = it;
-      const int row = it * RPI + rl;
-      const int64_t m = mw + row;
-      float v[W];
-#pragma unroll
-      for (int c = 0; c < W; c += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
-        v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
-      }
-      if (MODE == EPI_DACT) {
-        float u[8];
-        if (sizeof(CT) == 2) unpack8(side_h[bi], u);
-        else { u[0] = aux_f[bi][0]; u[1] = aux_f[bi][1]; u[2] = aux_f[bi][2]; u[3] = aux_f[bi][3]; }
-#pragma unroll
-        for (int c = 0; c < W; ++c) v[c] *= apply_act_grad(g.act, u[c]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < W; ++c) v[c] += bias[c];
-        if (MODE == EPI_ACT) {
-          if (g.aux) {
-            if (sizeof(CT) == 2) {
-              u32x4 p;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-              __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n));
-            } else {
-              __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
-                                          reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n));
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < W; ++c) v[c] = apply_act(g.act, v[c]);
-        }
-        if (g.residual) {
-          if (g.r_dtype == SEGCLIP_BF16) {
-            float rr[8];
-            if (W == 8) unpack8(side_h[bi], rr);
-            else { rr[0] = __uint_as_float(side_q[bi][0] << 16); rr[1] = __uint_as_float(side_q[bi][0] & 0xffff0000u);
-                   rr[2] = __uint_as_float(side_q[bi][1] << 16); rr[3] = __uint_as_float(side_q[bi][1] & 0xffff0000u); }
-#pragma unroll
-            for (int c = 0; c < W; ++c) v[c] += rr[c];
-          } else {
-#pragma unroll
-            for (int c = 0; c < W; ++c) v[c] += side_f[bi][c / 4][c % 4];
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < W; ++c) csum[c] += v[c];
-      if (sizeof(CT) == 2) {
-        u32x4 p;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-        // non-temporal: the output is not re-read by this kernel and should not displace the W tiles in L2
-        // (measured -0.4 ms per training step)
-        __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n));
-      } else {
-        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
-                                    reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n));
-      }
-    }
-  }
-  if (g.colsum_part) {  // column sums of this wave's 64 rows (bias gradient of the producing Linear)
-#pragma unroll
-    for (int c = 0; c < W; ++c) {
-      float x = csum[c];
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
-      if (rl == 0) g.colsum_part[(mw >> 6) * g.N + n + c] = x;
-    }
-  }
 }
 
-// epilogue_lds without residual / act' operands (bias, activation + pre-activation copy, column sums): rows are
-// processed by a rolled loop, 4 at a time (fully unrolling it, as the side-operand form above does, spilled registers
-// and cost the QuickGELU epilogue +25 %).
+// row pass with side operands (act' multiplier or residual) held in sr[]: fully unrolled
 template <typename CT, int MODE, int NSPLIT>
-__device__ __forceinline__ void epilogue_lds_plain(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
-                                                   int64_t nw, int lane, int64_t coff) {
-  const int li = lane & 31, lk = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
-  __builtin_amdgcn_wave_barrier();
-  constexpr int W = sizeof(CT) == 2 ? 8 : 4;
-  constexpr int LPR = 64 / W;
-  constexpr int RPI = 64 / LPR;
-  const int cl = lane % LPR, rl = lane / LPR;
-  const int64_t n = NSPLIT > 0 ? nw + ((cl * W) >> 5) * NSPLIT + ((cl * W) & 31) : nw + cl * W;
-  float bias[W];
-#pragma unroll
-  for (int c = 0; c < W; ++c) bias[c] = 0.f;
-  if (g.bias) {
-#pragma unroll
-    for (int c = 0; c < W; c += 4) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n + c);
-      bias[c] = b[0]; bias[c + 1] = b[1]; bias[c + 2] = b[2]; bias[c + 3] = b[3];
-    }
-  }
-  float csum[W];
+__device__ __forceinline__ void epi_rows_side(const Args& g, const typename EpiSideT<CT>::type (&sr)[EpiGeom<CT>::NIT],
+                                              const float* t, int64_t mw, int64_t nw, int lane, int64_t coff) {
+  using G = EpiGeom<CT>;
+  constexpr int W = G::W;
+  const int cl = lane % G::LPR, rl = lane / G::LPR;
+  const int64_t n = epi_col<CT, NSPLIT>(nw, cl);
+  float bias[W], csum[W];
+  epi_load_bias<CT, MODE>(g, bias, n);
 #pragma unroll
   for (int c = 0; c < W; ++c) csum[c] = 0.f;
-  constexpr int NIT = 64 / RPI, BATCH = 4;
+#pragma unroll
+  for (int it = 0; it < G::NIT; ++it) {
+    const int row = it * G::RPI + rl;
+    const int64_t m = mw + row;
+    float v[W];
+#pragma unroll
+    for (int c = 0; c < W; c += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
+      v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
+    }
+    float sd[W];   // exactly W entries: a wider array makes VectorCombine widen the side-register loads (-> scratch)
+    epi_side_get<CT>(sr[it], sd);
+    if (MODE == EPI_DACT) {
+#pragma unroll
+      for (int c = 0; c < W; ++c) v[c] *= dact_from_side(g.act, g.aux_kind, sd[c]);
+    } else {
+      epi_finish_row<CT, MODE>(g, v, bias, csum, m, n, coff);
+#pragma unroll
+      for (int c = 0; c < W; ++c) v[c] += sd[c];
+    }
+#pragma unroll
+    for (int c = 0; c < W; ++c) csum[c] += v[c];
+    epi_store_row<CT>(g, v, m, n, coff);
+  }
+  epi_colsum<CT>(g, csum, mw, n, rl);
+}
+
+// row pass without residual / act' operands (bias, activation + saved copy, column sums): rows are processed by a
+// rolled loop, 4 at a time (fully unrolling it, as the side-operand form above does, spilled registers and cost the
+// QuickGELU epilogue +25 %).
+template <typename CT, int MODE, int NSPLIT>
+__device__ __forceinline__ void epi_rows_plain(const Args& g, const float* t, int64_t mw, int64_t nw, int lane, int64_t coff) {
+  using G = EpiGeom<CT>;
+  constexpr int W = G::W;
+  const int cl = lane % G::LPR, rl = lane / G::LPR;
+  const int64_t n = epi_col<CT, NSPLIT>(nw, cl);
+  float bias[W], csum[W];
+  epi_load_bias<CT, MODE>(g, bias, n);
+#pragma unroll
+  for (int c = 0; c < W; ++c) csum[c] = 0.f;
+  constexpr int BATCH = 4;
 #pragma unroll 1
-  for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+  for (int it0 = 0; it0 < G::NIT; it0 += BATCH) {
 #pragma unroll
     for (int bi = 0; bi < BATCH; ++bi) {
-      const int row = (it0 + bi) * RPI + rl;
+      const int row = (it0 + bi) * G::RPI + rl;
       const int64_t m = mw + row;
       float v[W];
 #pragma unroll
@@ -301,45 +324,69 @@ __device__ __forceinline__ void epilogue_lds_plain(const Args& g, const f32x16 (
         const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
         v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
       }
-#pragma unroll
-      for (int c = 0; c < W; ++c) v[c] += bias[c];
-      if (MODE == EPI_ACT) {
-        if (g.aux) {
-          if (sizeof(CT) == 2) {
-            u32x4 p;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-            __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.aux + coff + m * g.ldaux + n));
-          } else {
-            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
-                                        reinterpret_cast<f32x4*>((float*)g.aux + coff + m * g.ldaux + n));
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < W; ++c) v[c] = apply_act(g.act, v[c]);
-      }
+      epi_finish_row<CT, MODE>(g, v, bias, csum, m, n, coff);
 #pragma unroll
       for (int c = 0; c < W; ++c) csum[c] += v[c];
-      if (sizeof(CT) == 2) {
-        u32x4 p;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) p[c] = pack2bf(v[2 * c], v[2 * c + 1]);
-        __builtin_nontemporal_store(p, reinterpret_cast<u32x4*>((bf16_t*)g.C + coff + m * g.ldc + n));
-      } else {
-        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]},
-                                    reinterpret_cast<f32x4*>((float*)g.C + coff + m * g.ldc + n));
-      }
+      epi_store_row<CT>(g, v, m, n, coff);
     }
   }
-  if (g.colsum_part) {
-#pragma unroll
-    for (int c = 0; c < W; ++c) {
-      float x = csum[c];
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
-      if (rl == 0) g.colsum_part[(mw >> 6) * g.N + n + c] = x;
-    }
+  epi_colsum<CT>(g, csum, mw, n, rl);
+}
+
+// one sub-tile (gemm_bf16_dma.hip)
+template <typename CT, int MODE, int NSPLIT = 0>
+__device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
+                                             int lane, int64_t coff, int64_t roff) {
+  if (MODE != EPI_DACT && !g.residual) {
+    epi_park(g, acc, t, lane);
+    __builtin_amdgcn_wave_barrier();
+    epi_rows_plain<CT, MODE, NSPLIT>(g, t, mw, nw, lane, coff);
+    return;
   }
+  typename EpiSideT<CT>::type sr[EpiGeom<CT>::NIT];
+  epi_side_load<CT, MODE, NSPLIT>(g, sr, mw, nw, lane, coff, roff);
+  epi_park(g, acc, t, lane);
+  __builtin_amdgcn_wave_barrier();
+  epi_rows_side<CT, MODE, NSPLIT>(g, sr, t, mw, nw, lane, coff);
+}
+
+// two sub-tiles of one wave (gemm_bf16_p8.hip: rows mw0.. and mw1..): the side loads of the second are issued as soon
+// as the first sub-tile's accumulators are parked, and land under the first row pass
+template <typename CT, int MODE, int NSPLIT>
+__device__ __forceinline__ void epilogue_lds2(const Args& g, const f32x16 (&acc0)[2][2], const f32x16 (&acc1)[2][2],
+                                              float* t, int64_t mw0, int64_t mw1, int64_t nw, int lane, int64_t coff,
+                                              int64_t roff) {
+  if (MODE != EPI_DACT && !g.residual) {
+    epi_park(g, acc0, t, lane);
+    __builtin_amdgcn_wave_barrier();
+    epi_rows_plain<CT, MODE, NSPLIT>(g, t, mw0, nw, lane, coff);
+    __builtin_amdgcn_wave_barrier();
+    epi_park(g, acc1, t, lane);
+    __builtin_amdgcn_wave_barrier();
+    epi_rows_plain<CT, MODE, NSPLIT>(g, t, mw1, nw, lane, coff);
+    return;
+  }
+#ifndef EPI_F32_OVERLAP
+#define EPI_F32_OVERLAP 0
+#endif
+  if (sizeof(CT) == 4 && !EPI_F32_OVERLAP) {
+    // fp32 side operands are 64 VGPRs per sub-tile: with the second sub-tile's accumulators still live there is no room
+    // for both, so the sub-tiles run one after the other (their side tile was touched into L2 / MALL at kernel start)
+    epilogue_lds<CT, MODE, NSPLIT>(g, acc0, t, mw0, nw, lane, coff, roff);
+    __builtin_amdgcn_wave_barrier();
+    epilogue_lds<CT, MODE, NSPLIT>(g, acc1, t, mw1, nw, lane, coff, roff);
+    return;
+  }
+  typename EpiSideT<CT>::type s0[EpiGeom<CT>::NIT], s1[EpiGeom<CT>::NIT];
+  epi_side_load<CT, MODE, NSPLIT>(g, s0, mw0, nw, lane, coff, roff);
+  epi_park(g, acc0, t, lane);
+  epi_side_load<CT, MODE, NSPLIT>(g, s1, mw1, nw, lane, coff, roff);
+  __builtin_amdgcn_wave_barrier();
+  epi_rows_side<CT, MODE, NSPLIT>(g, s0, t, mw0, nw, lane, coff);
+  __builtin_amdgcn_wave_barrier();
+  epi_park(g, acc1, t, lane);
+  __builtin_amdgcn_wave_barrier();
+  epi_rows_side<CT, MODE, NSPLIT>(g, s1, t, mw1, nw, lane, coff);
 }
 
 template <typename CT, int NSPLIT = 0>
@@ -348,6 +395,14 @@ __device__ __forceinline__ void epilogue_lds_mode(const Args& g, const f32x16 (&
   if (g.mul_dact) epilogue_lds<CT, EPI_DACT, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
   else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds<CT, EPI_ACT, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
   else epilogue_lds<CT, EPI_PLAIN, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
+}
+template <typename CT, int NSPLIT>
+__device__ __forceinline__ void epilogue_lds2_mode(const Args& g, const f32x16 (&acc0)[2][2], const f32x16 (&acc1)[2][2],
+                                                   float* t, int64_t mw0, int64_t mw1, int64_t nw, int lane,
+                                                   int64_t coff, int64_t roff) {
+  if (g.mul_dact) epilogue_lds2<CT, EPI_DACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff);
+  else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds2<CT, EPI_ACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff);
+  else epilogue_lds2<CT, EPI_PLAIN, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff);
 }
 
 }  // namespace

@@ -344,6 +344,7 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
     g.vec_epi = al(d->C) && al(d->aux) && al(d->residual) && al(d->bias) && d->ldc % ce == 0 &&
                 (!d->aux || d->ldaux % ce == 0) && (!d->residual || d->ldr % re == 0) && d->bsC1 % ce == 0 &&
                 d->bsC2 % ce == 0 && (!d->residual || (d->bsR1 % re == 0 && d->bsR2 % re == 0));
+    if (d->residual && d->r_dtype != d->c_dtype) g.vec_epi = 0;   // the LDS epilogue holds side operands in the output type
     if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);

@@ -122,7 +122,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 template <bool A_KS, bool B_KS, int ABL = 0>
 __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   constexpr int LDS_BYTES = RING > NWV * EPI_WAVE_BYTES ? RING : NWV * EPI_WAVE_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 256];   // + junk slot of the side-tile touches
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -166,6 +166,36 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
     if (u < 2) dma16x2(baseA + (int64_t)t * stepA, offA[u][0], offA[u][1], dst);
     else dma16x2(baseB + (int64_t)t * stepB, offB[u - 2][0], offB[u - 2][1], dst);
   };
+
+  // EXPERIMENT, off by default (SEGCLIP_P8_TOUCH=1): side tile of the epilogue (saved activation of the act' dgrad, or
+  // the residual): every 64-byte sector of the tile's 256 rows is touched once now by a 4-byte LDS-DMA into a junk LDS
+  // slot (no VGPR destination), so that the lines travel HBM -> MALL/L2 while the K loop runs.  The touches are the
+  // oldest entries of the in-order VM queue: the first counted wait of the prologue covers them.  Measured on MI355X
+  // (tools/bench_epi.py, M = 50176): SLOWER - out_proj +fp32 residual 89.8 -> 114.1 us, c_proj +residual 253 -> 268,
+  // act' dgrad 326 -> 340: the epilogue is not waiting for the latency of these loads.
+  if (g.touch && g.splits == 1 && (g.mul_dact || g.residual) && n0 + BT <= g.N) {
+    const int esz = g.mul_dact ? (g.c_dtype == SEGCLIP_BF16 ? 2 : 4) : (g.r_dtype == SEGCLIP_BF16 ? 2 : 4);
+    const int64_t pitch = (g.mul_dact ? g.ldaux : g.ldr) * esz;
+    const char* sp = g.mul_dact ? reinterpret_cast<const char*>(g.aux) + (coff + m0 * g.ldaux + n0) * esz
+                                : reinterpret_cast<const char*>(g.residual) + (roff + m0 * g.ldr + n0) * esz;
+    const int spr_log = esz == 2 ? 3 : 4;               // 64-byte sectors per tile row: 8 (bf16) / 16 (fp32)
+    const int total = BT << spr_log;
+    const int64_t rmax = g.M - 1 - m0;
+    const uint32_t junk = (uint32_t)(uintptr_t)((lds_void*)smem) + LDS_BYTES;
+    for (int sidx = tid; sidx < total; sidx += NWV * 64) {
+      int64_t row = sidx >> spr_log;
+      row = row < rmax ? row : rmax;
+      const uint32_t off = (uint32_t)(row * pitch + ((sidx & ((1 << spr_log) - 1)) << 6));
+      asm volatile(
+          "s_nop 4\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dword %0, %1"
+          :
+          : "v"(off), "s"(sp), "s"(junk)
+          : "memory");
+    }
+  }
 
   f32x16 acc[2][2][2];  // [A half][32-row tile][B half]
 #pragma unroll
@@ -306,22 +336,36 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   const bool vec = full && g.vec_epi;
   if (vec) __syncthreads();  // every wave is done with the operand ring: the LDS is reused as 8 private patches
   float* tp = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+  const int64_t mw0 = m0 + wr * 64, mw1 = m0 + 128 + wr * 64;
+  if (vec) {
+#ifdef P8_TEST_SINGLE
+    if (g.c_dtype == SEGCLIP_BF16) { epilogue_lds_mode<bf16_t, 128>(g, acc[0], tp, mw0, nw, lane, coff, roff); __builtin_amdgcn_wave_barrier(); epilogue_lds_mode<bf16_t, 128>(g, acc[1], tp, mw1, nw, lane, coff, roff); }
+    else { epilogue_lds_mode<float, 128>(g, acc[0], tp, mw0, nw, lane, coff, roff); __builtin_amdgcn_wave_barrier(); epilogue_lds_mode<float, 128>(g, acc[1], tp, mw1, nw, lane, coff, roff); }
+#else
+    if (g.c_dtype == SEGCLIP_BF16) epilogue_lds2_mode<bf16_t, 128>(g, acc[0], acc[1], tp, mw0, mw1, nw, lane, coff, roff);
+    else epilogue_lds2_mode<float, 128>(g, acc[0], acc[1], tp, mw0, mw1, nw, lane, coff, roff);
+#endif
+#ifndef P8_TEST_NORETURN
+    return;
+#endif
+  }
+#ifdef P8_TEST_NORETURN
+  else {
+#endif
   // two explicit copies (a loop over the A half would index the accumulators at run time -> scratch)
 #define P8_EPI(I)                                                                                              \
   do {                                                                                                         \
     const int64_t mw = m0 + (I) * 128 + wr * 64;                                                               \
-    if (vec) {                                                                                                 \
-      if (g.c_dtype == SEGCLIP_BF16) epilogue_lds_mode<bf16_t, 128>(g, acc[I], tp, mw, nw, lane, coff, roff);  \
-      else epilogue_lds_mode<float, 128>(g, acc[I], tp, mw, nw, lane, coff, roff);                             \
-    } else {                                                                                                   \
-      if (g.c_dtype == SEGCLIP_BF16) epilogue_mode<bf16_t, false>(g, acc[I], mw, nw, 0, 0, lane, coff, roff, 128); \
-      else epilogue_mode<float, false>(g, acc[I], mw, nw, 0, 0, lane, coff, roff, 128);                        \
-    }                                                                                                          \
+    if (g.c_dtype == SEGCLIP_BF16) epilogue_mode<bf16_t, false>(g, acc[I], mw, nw, 0, 0, lane, coff, roff, 128); \
+    else epilogue_mode<float, false>(g, acc[I], mw, nw, 0, 0, lane, coff, roff, 128);                          \
   } while (0)
   P8_EPI(0);
   __builtin_amdgcn_wave_barrier();
   P8_EPI(1);
 #undef P8_EPI
+#ifdef P8_TEST_NORETURN
+  }
+#endif
 }
 
 }  // namespace
@@ -382,6 +426,8 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   // 32-bit DMA offsets: 256 rows (or 64 k-rows) of the leading dimension must stay below 4 GiB
   if ((a_ks ? 64 : 256) * (a_ks ? d->sak : d->sam) * 2 >= (int64_t)1 << 31) return false;
   if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
+  static const int touch = [] { const char* e = getenv("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
+  g.touch = touch;
   g.nbx = (int)cdiv(d->N, BT);
   g.nby = (int)cdiv(d->M, BT);
   g.splits = splits;
@@ -392,6 +438,7 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
     g.vec_epi = al(d->C) && al(d->aux) && al(d->residual) && al(d->bias) && d->ldc % ce == 0 &&
                 (!d->aux || d->ldaux % ce == 0) && (!d->residual || d->ldr % re == 0) && d->bsC1 % ce == 0 &&
                 d->bsC2 % ce == 0 && (!d->residual || (d->bsR1 % re == 0 && d->bsR2 % re == 0));
+    if (d->residual && d->r_dtype != d->c_dtype) g.vec_epi = 0;   // the LDS epilogue holds side operands in the output type
     if (g.colsum_part && !g.vec_epi) return false;
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);

@@ -16,7 +16,7 @@ struct GemmArgs {
   const float* bias; const float* residual; float* aux;
   int64_t M, N, K, sam, sak, sbn, sbk, ldc, ldr, ldaux;
   int64_t nb2, bsA1, bsA2, bsB1, bsB2, bsC1, bsC2, bsR1, bsR2;
-  int act, mul_dact; float alpha;
+  int act, mul_dact, aux_kind; float alpha;
 };
 
 // stage a [rows x BK] tile of X(row,k) = X[row*sr + k*sk] into lds[k][row]
@@ -121,11 +121,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
         if (m >= g.M) continue;
         float v = g.alpha * acc[i][j][r];
         if (g.mul_dact) {
-          v *= apply_act_grad(g.act, g.aux[coff + m * g.ldaux + n]);
+          const float sd = g.aux[coff + m * g.ldaux + n];
+          v *= g.aux_kind ? sd : apply_act_grad(g.act, sd);
         } else {
           v += bv;
           if (g.act != SEGCLIP_ACT_NONE) {
-            if (g.aux) g.aux[coff + m * g.ldaux + n] = v;
+            if (g.aux) g.aux[coff + m * g.ldaux + n] = g.aux_kind ? apply_act_grad(g.act, v) : v;
             v = apply_act(g.act, v);
           }
           if (g.residual) v += g.residual[roff + m * g.ldr + n];
@@ -145,7 +146,7 @@ int segclip_gemm_f32_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.ldc = d->ldc; g.ldr = d->ldr; g.ldaux = d->ldaux;
   g.nb2 = d->nb2 > 0 ? d->nb2 : 1;
   g.bsA1 = d->bsA1; g.bsA2 = d->bsA2; g.bsB1 = d->bsB1; g.bsB2 = d->bsB2; g.bsC1 = d->bsC1; g.bsC2 = d->bsC2; g.bsR1 = d->bsR1; g.bsR2 = d->bsR2;
-  g.act = d->act; g.mul_dact = d->mul_dact; g.alpha = d->alpha;
+  g.act = d->act; g.mul_dact = d->mul_dact; g.aux_kind = d->aux_kind; g.alpha = d->alpha;
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * g.nb2;
   dim3 grid((unsigned)cdiv(d->N, BN), (unsigned)cdiv(d->M, BM), (unsigned)nb);
   SEGCLIP_REQUIRE(grid.y <= 65535 && nb <= 65535, "gemm_f32: grid too large (M=%lld batch=%lld)",

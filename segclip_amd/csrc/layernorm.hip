@@ -2,6 +2,8 @@
 // (cols <= 2048), fp32 statistics, 16-byte (fp32) / 8-byte (bf16) vector loads, wave shuffles for the
 // two reductions.  Backward fuses the residual-gradient add (dx = LN'(dy) + dres) and produces
 // dgamma/dbeta through a deterministic two-stage reduction (per-block partials -> column sums).
+#include <stdlib.h>
+
 #include "common.h"
 #include "reduce_rows.h"
 
@@ -78,37 +80,82 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const void* __restri
   }
 }
 
-template <int NV>
+// raw (as loaded) 4-element group of a row: fp32 -> 16 bytes, bf16 -> 8 bytes; converted where it is consumed, so the
+// software pipeline below keeps the NEXT row in half the registers
+template <int DT> struct Raw4;
+template <> struct Raw4<SEGCLIP_F32> {
+  f32x4 v;
+  __device__ __forceinline__ void ld(const void* base, int64_t idx) { v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx); }
+  __device__ __forceinline__ f32x4 get() const { return v; }
+};
+template <> struct Raw4<SEGCLIP_BF16> {
+  u32x2 v;
+  __device__ __forceinline__ void ld(const void* base, int64_t idx) { v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(base) + idx); }
+  __device__ __forceinline__ f32x4 get() const {
+    return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                 __uint_as_float(v[1] & 0xffff0000u)};
+  }
+};
+
+// Backward.  One wave per row; a wave walks rows  blockIdx*WAVES + wave + k*gridDim*WAVES  with a two-deep software
+// pipeline: ALL loads of row k+1 (x, dy, dres, mean, rstd) are issued before row k is reduced and stored, so every
+// wave always has a full row (10-16 bytes per element) in flight and the two dependent wave reductions of a row are
+// covered by the next row's memory time (the first version issued the dres load after the reductions: two exposed
+// round trips per row, 3.3-3.5 TB/s).  gamma stays in registers.  Element types are template parameters (raw bf16
+// data is kept packed until used).  HAS_RES: dx += dres, and the column sums of dres are accumulated.
+template <int NV, int DYD, int XD, int DXD, bool HAS_RES, bool HAS_DX2>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const void* __restrict__ dres, void* __restrict__ dx,
                                                             void* __restrict__ dx2, float* __restrict__ part,
-                                                            int64_t rows, int cols, int dyd, int xd, int dxd) {
+                                                            int64_t rows, int cols) {
   __shared__ float red[WAVES][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int nv = NV;
-  f32x4 ag[NV], ab[NV], ar[NV];
+  f32x4 ag[NV], ab[NV], ar[NV], gm[NV];
+  bool on[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ar[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int c = (lane + 64 * i) * 4;
+    on[i] = c < cols;
+    gm[i] = on[i] ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < rows; row += (int64_t)gridDim.x * WAVES) {
-    const float mu = mean[row], rs = rstd[row];
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+  Raw4<XD> nx[NV]; Raw4<DYD> nd[NV]; Raw4<DXD> nr[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto issue = [&](int64_t r) {
+    nmu = mean[r]; nrs = rstd[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (on[i]) {
+        const int64_t idx = r * cols + (lane + 64 * i) * 4;
+        nx[i].ld(x, idx);
+        nd[i].ld(dy, idx);
+        if (HAS_RES) nr[i].ld(dres, idx);
+      }
+    }
+  };
+  if (row < rows) issue(row);
+  for (; row < rows; row += stride) {
+    // take over the landed row, then put the next one in flight
+    Raw4<XD> cx[NV]; Raw4<DYD> cd[NV]; Raw4<DXD> cr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; if (HAS_RES) cr[i] = nr[i]; }
+    const float mu = nmu, rs = nrs;
+    if (row + stride < rows) issue(row + stride);
     f32x4 xh[NV], gg[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (i < nv && c < cols) {
-        const f32x4 xv = load4(x, xd, row * cols + c);
-        const f32x4 d = load4(dy, dyd, row * cols + c);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      if (on[i]) {
+        const f32x4 xv = cx[i].get(), d = cd[i].get();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           xh[i][j] = (xv[j] - mu) * rs;
-          gg[i][j] = d[j] * g[j];
+          gg[i][j] = d[j] * gm[i][j];
           s1 += gg[i][j];
           s2 += gg[i][j] * xh[i][j];
           ag[i][j] += d[j] * xh[i][j];
@@ -119,25 +166,25 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
     const float c1 = wave_sum(s1) / cols, c2 = wave_sum(s2) / cols;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (i < nv && c < cols) {
+      if (on[i]) {
+        const int64_t idx = row * cols + (lane + 64 * i) * 4;
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rs * (gg[i][j] - c1 - xh[i][j] * c2);
-        if (dres) {
-          const f32x4 r = load4(dres, dxd, row * cols + c);
+        if (HAS_RES) {
+          const f32x4 r = cr[i].get();
 #pragma unroll
           for (int j = 0; j < 4; ++j) { o[j] += r[j]; ar[i][j] += r[j]; }
         }
-        store4(dx, dxd, row * cols + c, o);
-        if (dx2) store4(dx2, SEGCLIP_BF16, row * cols + c, o);
+        store4(dx, DXD, idx, o);
+        if (HAS_DX2) store4(dx2, SEGCLIP_BF16, idx, o);
       }
     }
   }
   // block partials: part[blockIdx][0] = dgamma, [1] = dbeta, [2] = column sums of dres
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < (HAS_RES ? 3 : 2); ++pass) {
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = pass == 0 ? ag[i][j] : (pass == 1 ? ab[i][j] : ar[i][j]);
@@ -158,9 +205,11 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const void* __restri
   }
 }
 
+// 3 workgroups of 4 waves per CU (the pipelined kernel holds two rows per wave: ~130 VGPRs at 768 columns)
 int ln_blocks(int64_t rows) {
+  static const int cap = [] { const char* e = getenv("SEGCLIP_LN_BLOCKS"); return e ? atoi(e) : 768; }();
   int64_t b = cdiv(rows, WAVES);
-  return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
+  return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
 }
 
 }  // namespace
@@ -196,13 +245,39 @@ extern "C" int segclip_layernorm_bwd(const void* dy, const void* x, const float*
   SEGCLIP_REQUIRE(ws != nullptr, "layernorm_bwd: workspace required");
   if (rows == 0) return 0;
   const int nb = ln_blocks(rows);
-#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(nb), dim3(WAVES * 64), 0, (hipStream_t)stream, dy, x, gamma, \
-                                   mean, rstd, dres, dx, dx_bf16, (float*)ws, rows, (int)cols, dy_dtype, x_dtype, dx_dtype)
+  const bool has_res = dres != nullptr, has_dx2 = dx_bf16 != nullptr;
+  SEGCLIP_REQUIRE(x_dtype == SEGCLIP_F32 || x_dtype == SEGCLIP_BF16, "layernorm_bwd: bad x dtype");
+#define LNB4(NV, DYD, XD, DXD)                                                                                         \
+  do {                                                                                                                 \
+    if (has_res && has_dx2) LNBK(NV, DYD, XD, DXD, true, true);                                                        \
+    else if (has_res) LNBK(NV, DYD, XD, DXD, true, false);                                                             \
+    else if (has_dx2) LNBK(NV, DYD, XD, DXD, false, true);                                                             \
+    else LNBK(NV, DYD, XD, DXD, false, false);                                                                         \
+  } while (0)
+#define LNBK(NV, DYD, XD, DXD, R, D2)                                                                                   \
+  hipLaunchKernelGGL((ln_bwd_kernel<NV, DYD, XD, DXD, R, D2>), dim3(nb), dim3(WAVES * 64), 0, (hipStream_t)stream, dy, x, \
+                     gamma, mean, rstd, dres, dx, dx_bf16, (float*)ws, rows, (int)cols)
+#define LNB(NV)                                                                                                        \
+  do {                                                                                                                 \
+    const int key = (dy_dtype << 2) | (x_dtype << 1) | dx_dtype;                                                       \
+    switch (key) {                                                                                                     \
+      case 0: LNB4(NV, SEGCLIP_F32, SEGCLIP_F32, SEGCLIP_F32); break;                                                  \
+      case 1: LNB4(NV, SEGCLIP_F32, SEGCLIP_F32, SEGCLIP_BF16); break;                                                 \
+      case 2: LNB4(NV, SEGCLIP_F32, SEGCLIP_BF16, SEGCLIP_F32); break;                                                 \
+      case 3: LNB4(NV, SEGCLIP_F32, SEGCLIP_BF16, SEGCLIP_BF16); break;                                                \
+      case 4: LNB4(NV, SEGCLIP_BF16, SEGCLIP_F32, SEGCLIP_F32); break;                                                 \
+      case 5: LNB4(NV, SEGCLIP_BF16, SEGCLIP_F32, SEGCLIP_BF16); break;                                                \
+      case 6: LNB4(NV, SEGCLIP_BF16, SEGCLIP_BF16, SEGCLIP_F32); break;                                                \
+      default: LNB4(NV, SEGCLIP_BF16, SEGCLIP_BF16, SEGCLIP_BF16); break;                                              \
+    }                                                                                                                  \
+  } while (0)
   switch ((int)cdiv(cols / 4, 64)) {
     case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break;
     case 5: case 6: LNB(6); break; default: LNB(8); break;
   }
 #undef LNB
+#undef LNB4
+#undef LNBK
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd");
   launch_reduce_rows((const float*)ws, nb, (dres && dres_colsum ? 3 : 2) * cols, 3 * cols, dgamma, dbeta,
                      dres ? dres_colsum : nullptr, cols, (hipStream_t)stream);

@@ -22,8 +22,8 @@ ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = L.ACT_NONE, L.ACT_QUICK_GELU, L.ACT_GEL
 
 
 class _GemmProfile:
-    """Optional per-launch timing of the dominant (GEMM) kernel with HIP events on the launch stream
-    (bench.py's roofline leg).  Off by default; adds two event records per launch when enabled."""
+    """Optional per-launch timing of the dominant (GEMM) kernel with HIP events on the launch stream (tools/gemm_breakdown.py,
+    bench.py's fallback when rocprofv3 is not usable).  Off by default; adds two event records per launch when enabled."""
     enabled = False
     records = []  # (start_event, end_event, flops, is_bf16, algorithmic bytes)
 
@@ -38,6 +38,27 @@ class _GemmProfile:
         out = [(s.elapsed_time(e) * 1e-3, f, b, nb) for s, e, f, b, nb in cls.records]
         cls.records = []
         return out
+
+
+class _OpCount:
+    """Algorithmic work of one model pass, per kernel class (bench.py's roofline block divides it by the kernel time
+    rocprofv3 measured for the same class): records (class, flops, bytes) per launch, no device work.  Off by default."""
+    enabled = False
+    records = []
+
+    @classmethod
+    def start(cls):
+        cls.enabled, cls.records = True, []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        out, cls.records = cls.records, []
+        return out
+
+    @classmethod
+    def add(cls, kind, flops, nbytes):
+        cls.records.append((kind, float(flops), float(nbytes)))
 
 
 def _empty(shape, dtype, like):
@@ -56,7 +77,7 @@ def _off(t, off):
 # ------------------------------------------------------------------------------------------------
 def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=None, residual=None, ldr=0,
            r_off=0, aux=None, ldaux=0, act=ACT_NONE, mul_dact=False, alpha=1.0, nb1=1, nb2=1, bsA=(0, 0),
-           bsB=(0, 0), bsC=(0, 0), bsR=None, colsum=None):
+           bsB=(0, 0), bsC=(0, 0), bsR=None, colsum=None, aux_kind=0):
     """C(m,n) = epi(alpha * sum_k A(m,k) B(n,k)); sa = (sam, sak), sb = (sbn, sbk) element strides."""
     lib = L.load()
     L.require_cuda(A, B, Cc)
@@ -78,7 +99,7 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     d.r_dtype = L.dt(residual) if residual is not None else L.F32
     if aux is not None and aux.dtype != Cc.dtype:
         raise TypeError("gemm: aux dtype must equal output dtype")
-    d.act, d.mul_dact, d.alpha = act, int(mul_dact), float(alpha)
+    d.act, d.mul_dact, d.alpha, d.aux_kind = act, int(mul_dact), float(alpha), int(aux_kind)
     if colsum is not None:
         csws = torch.empty((max(M // 64, 1), N), dtype=torch.float32, device=A.device)
         d.colsum, d.colsum_ws = L.ptr(colsum), L.ptr(csws)
@@ -87,6 +108,12 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     if nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = L.ptr(ws), nbytes
+    if _OpCount.enabled:
+        nz = nb1 * nb2
+        _OpCount.add("gemm_bf16" if B.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * nz,
+                     nz * (M * K * A.element_size() + N * K * B.element_size() + M * N * Cc.element_size()
+                           + (M * N * residual.element_size() if residual is not None else 0)
+                           + (M * N * aux.element_size() if aux is not None else 0)))
     if _GemmProfile.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -117,8 +144,9 @@ def p_cast(t, dtype):
     return out
 
 
-def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_dtype=None, w_kn=False):
-    """y = act(x w^T + bias) + residual.  x (M,K) view; w (N,K) [or (K,N) when w_kn]; same dtype family."""
+def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_dtype=None, w_kn=False, aux_kind=0):
+    """y = act(x w^T + bias) + residual.  x (M,K) view; w (N,K) [or (K,N) when w_kn]; same dtype family.
+    want_aux: also return what the backward needs of the pre-activation u: u itself (aux_kind 0) or act'(u) (aux_kind 1)."""
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
     out_dtype = out_dtype or x.dtype
@@ -126,7 +154,7 @@ def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_d
     aux = _empty((M, N), out_dtype, x) if (want_aux and act != ACT_NONE) else None
     sb = (1, w.stride(0)) if w_kn else (w.stride(0), 1)
     p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, N, bias=bias, residual=residual,
-           ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=N, act=act)
+           ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=N, act=act, aux_kind=aux_kind)
     return y, aux
 
 
@@ -135,7 +163,7 @@ def fused_colsum_ok(M, N, K, dtype):
     return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0
 
 
-def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None):
+def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None, aux_kind=0):
     """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)
     want_colsum: also return the column sums of dx (= bias gradient of the Linear that produced the
     pre-activation), fused into the GEMM epilogue when the shape allows, else by the colsum kernel."""
@@ -148,7 +176,8 @@ def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=Fa
     cs = None
     if want_colsum and fused_colsum_ok(M, K, N, out_dtype) and dy.dtype == torch.bfloat16:
         cs = colsum_out if colsum_out is not None else _empty((K,), torch.float32, dy)
-    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None, colsum=cs)
+    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None, colsum=cs,
+           aux_kind=aux_kind)
     if want_colsum:
         return dx, (cs if cs is not None else p_colsum(dx, out=colsum_out))
     return dx
@@ -204,6 +233,8 @@ def p_ln_fwd(x, w, b, eps, out_dtype):
     y = _empty((rows, cols), out_dtype, x)
     mean = _empty((rows,), torch.float32, x)
     rstd = _empty((rows,), torch.float32, x)
+    if _OpCount.enabled:
+        _OpCount.add("ln_fwd", 0, rows * cols * (x.element_size() + y.element_size()))
     L.check(L.load().segclip_layernorm_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows,
                                            cols, eps, L.dt(x), L.dt(y), L.stream()), "layernorm_fwd")
     return y, mean, rstd
@@ -226,6 +257,9 @@ def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, wa
         dres = dres.contiguous()
         if dres.dtype != dx_dtype:
             raise TypeError("layernorm_bwd: dres dtype must equal dx dtype")
+    if _OpCount.enabled:
+        _OpCount.add("ln_bwd", 0, rows * cols * (dy.element_size() + x.element_size() + dx.element_size() * (2 if dres is not None else 1)
+                                                 + (2 if want_bf16 else 0)))
     ws = torch.empty(max(lib.segclip_layernorm_bwd_ws_bytes(rows, cols), 4), dtype=torch.uint8, device=x.device)
     L.check(lib.segclip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
                                       L.ptr(dx16), L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws), rows, cols, L.dt(dy),
@@ -261,6 +295,9 @@ def p_attn_fwd(d, like):
     lib = L.load()
     stats = torch.empty(max(lib.segclip_attn_stats_bytes(C.byref(d)) // 4, 1), dtype=torch.float32, device=like.device)
     d.stats = L.ptr(stats)
+    if _OpCount.enabled:   # QK^T + PV (causal: half), Q K V read + O written
+        fl = 4.0 * d.B * d.H * d.Tq * d.Tk * d.hd * (0.5 if d.causal else 1.0)
+        _OpCount.add("attn_fwd", fl, 2.0 * d.B * d.H * d.hd * (2 * d.Tq + 2 * d.Tk))
     L.check(lib.segclip_attn_fwd(C.byref(d), L.stream()), "attn_fwd")
     return stats
 
@@ -278,6 +315,9 @@ def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0,
     nbytes = lib.segclip_attn_bwd_ws_bytes(C.byref(d))
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=do.device)
     d.ws = L.ptr(ws)
+    if _OpCount.enabled:   # S, dP, dV, dK, dQ = 2.5 x forward; Q K V O dO read + dQ dK dV written
+        fl = 10.0 * d.B * d.H * d.Tq * d.Tk * d.hd * (0.5 if d.causal else 1.0)
+        _OpCount.add("attn_bwd", fl, 2.0 * d.B * d.H * d.hd * (4 * d.Tq + 4 * d.Tk))
     L.check(lib.segclip_attn_bwd(C.byref(d), L.stream()), "attn_bwd")
 
 
@@ -514,13 +554,20 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
     stats = p_attn_fwd(ad, x2)
     x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
     y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
-    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True)
+    # bf16 mode: the c_fc epilogue stores act'(u) (its exponential is already there), the c_proj dgrad multiplies by it
+    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act))
     xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
     saved = (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c)
     return xo, saved
 
 
 N_SAVED = 19
+
+
+def _aux_kind(act_dtype, act):
+    """What the residual blocks keep of the MLP pre-activation: act'(u) in bf16 mode with QuickGELU (the towers), u itself
+    in the exact-f32 mode and for the erf-GELU of the MAE decoders."""
+    return 1 if (act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU) else 0
 
 
 def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False):
@@ -564,7 +611,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
 
     # ---- MLP
     du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
-                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None)  # (dy c_proj)*act'(u), colsum
+                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None, aux_kind=_aux_kind(act_dtype, act))  # (dy c_proj)*act'(u), colsum
     dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)))) if need[11] else None
     dy2 = p_dgrad(du, wfc_c, act_dtype)
     dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)))) if need[9] else None

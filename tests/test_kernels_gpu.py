@@ -87,6 +87,31 @@ def test_gemm_fused_colsum_epilogue():
     close(cs2, ref[:200].sum(0), 2e-2, 0.05, "fallback colsum")
 
 
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (200, 136, 72), (784, 3072, 768), (256, 128, 64)])
+def test_gemm_saved_activation_derivative(dtype, M, N, K):
+    """aux_kind 1: the activation epilogue stores act'(u) instead of u, the act' dgrad multiplies by it as it is
+    (what the residual blocks do in bf16 mode); every bf16 kernel (8-phase, one-barrier DMA, register-staged) + f32."""
+    x, w, b = rnd(M, K, dtype=dtype, seed=51), rnd(N, K, dtype=dtype, seed=52, scale=K ** -0.5), rnd(N, seed=53)
+    pre = x.float() @ w.float().t() + b
+    sg = torch.sigmoid(1.702 * pre)
+    dref = sg * (1 + 1.702 * pre * (1 - sg))
+    rt, at = TOL[dtype]
+    y, a1 = ops.p_linear(x, w, b, act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=1)
+    close(y, pre * sg, rt, at, "act")
+    close(a1, dref, rt, at, "saved derivative")
+    y0, a0 = ops.p_linear(x, w, b, act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=0)
+    close(a0, pre, rt, at, "saved pre-activation")
+    assert torch.equal(y0, y)
+    g, w2 = rnd(M, K, dtype=dtype, seed=54), rnd(K, N, dtype=dtype, seed=55, scale=K ** -0.5)   # c_proj: (D, 4D)
+    du1 = ops.p_dgrad(g, w2, dtype, aux=a1, act=ops.ACT_QUICK_GELU, aux_kind=1)
+    close(du1, (g.float() @ w2.float()) * a1.float(), rt, at * 2, "dgrad * saved derivative")
+    du0 = ops.p_dgrad(g, w2, dtype, aux=a0, act=ops.ACT_QUICK_GELU, aux_kind=0)
+    close(du0, du1, 3 * rt, at * 4, "both kinds agree")
+    with pytest.raises(RuntimeError):       # erf-GELU keeps the pre-activation
+        ops.p_linear(x, w, b, act=ops.ACT_GELU_ERF, want_aux=True, aux_kind=1)
+
+
 def test_gemm_bf16_fp32_A_operand_and_splitk():
     """fp32 residual-stream gradients as the A operand of the bf16 kernels; split-K wgrad (M >> tiles)."""
     M, N, K = 6272, 256, 128
@@ -143,6 +168,33 @@ def test_layernorm_fwd_bwd(cols, xdt, ydt):
     close(dsum, dres.sum(0), 1e-5, 1e-4, "ln colsum(dres)")
     close(dw, wr.grad, 1e-4, 1e-3, "ln dgamma")
     close(db, br.grad, 1e-4, 1e-3, "ln dbeta")
+
+
+@pytest.mark.parametrize("rows,cols", [(197, 768), (5000, 768), (77 * 9, 512), (64, 1024)])
+@pytest.mark.parametrize("resdt", [None, F32, BF])
+def test_layernorm_bwd_pipelined_variants(rows, cols, resdt):
+    """The software-pipelined backward in the dtype combinations of the training step: bf16 dy, fp32 x, residual
+    gradient / dx in fp32 (+ bf16 copy) or bf16 (the in-tower chain), with and without dres; more rows than
+    waves in flight, so every wave walks several rows."""
+    x = rnd(rows, cols, dtype=F32, seed=36)
+    w, b = 1 + 0.1 * rnd(cols, seed=37), 0.1 * rnd(cols, seed=38)
+    y, mean, rstd = ops.p_ln_fwd(x, w, b, 1e-5, BF)
+    dy = rnd(rows, cols, dtype=BF, seed=39)
+    xr = x.clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (cols,), wr, br, 1e-5).backward(dy.float())
+    dres = rnd(rows, cols, dtype=resdt, seed=40) if resdt is not None else None
+    dxd = resdt or F32
+    out = ops.p_ln_bwd(dy, x, w, mean, rstd, dres=dres, dx_dtype=dxd, want_bf16=(dxd == F32), want_dres_colsum=dres is not None)
+    want = xr.grad + (dres.float() if dres is not None else 0)
+    rt, at = (1e-4, 1e-4) if dxd == F32 else (1e-2, 1e-2)
+    close(out[0], want, rt, at, "ln dx")
+    if dxd == F32:
+        assert torch.equal(out[3], out[0].to(BF))
+    if dres is not None:
+        close(out[-1], dres.float().sum(0), 1e-5, 1e-3 * rows ** 0.5, "colsum(dres)")
+    close(out[1], wr.grad, 1e-4, 1e-3 * rows ** 0.5, "ln dgamma")
+    close(out[2], br.grad, 1e-4, 1e-3 * rows ** 0.5, "ln dbeta")
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -1,0 +1,142 @@
+"""Kernel-time roofline of one bench step, measured by rocprofv3 (used by bench.py and tools/profile_round.sh).
+
+bench.py re-runs its own workload for a few steps as a child process under `rocprofv3 --kernel-trace`, and once
+more under `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate, counters-only passes, as MI355X_MICROARCH.md's HBM
+section prescribes).  This module starts those children, reads the rocpd sqlite database / counter CSVs they leave
+behind, groups the dispatches into kernel classes and turns them into per-step kernel times - the SAME numbers
+`rocprofv3 --stats` prints, so the bench line can be recomputed from the summary committed under profiles/.
+"""
+import csv
+import glob
+import os
+import shutil
+import sqlite3
+import subprocess
+import sys
+import tempfile
+
+# kernel class -> substrings of the kernel name
+CLASSES = [
+    ("gemm_bf16", ("gemm_bf16_p8_kernel", "gemm_bf16_dma_kernel", "gemm_bf16_kernel")),
+    ("splitk_reduce", ("splitk_reduce",)),
+    ("gemm_f32", ("gemm_f32_kernel",)),
+    ("attn_fwd", ("attn_fwd",)),
+    ("attn_bwd", ("attn_bwd",)),
+    ("ln_fwd", ("ln_fwd_kernel",)),
+    ("ln_bwd", ("ln_bwd_kernel",)),
+    ("row_reductions", ("reduce_rows_kernel", "colsum_partial_kernel")),
+]
+
+
+def classify(name):
+    for cls, pats in CLASSES:
+        if any(p in name for p in pats):
+            return cls
+    return "other"
+
+
+def rocprofv3_path():
+    return shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+
+
+def run_child(child_argv, outdir, pmc=None, timeout=300):
+    """Run `python <child_argv>` under rocprofv3.  pmc=None: kernel trace (rocpd database); pmc='FETCH_SIZE': a
+    counters-only pass (CSV).  Returns (returncode, stdout, stderr-tail)."""
+    exe = rocprofv3_path()
+    if exe is None:
+        raise RuntimeError("rocprofv3 not found")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT",
+              "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(k, None)
+    cmd = [exe]
+    cmd += ["--pmc", pmc, "--output-format", "csv"] if pmc else ["--kernel-trace", "--stats"]
+    cmd += ["-d", outdir, "-o", "rl", "--", sys.executable] + list(child_argv)
+    pr = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    return pr.returncode, pr.stdout, pr.stderr[-2000:]
+
+
+def find_db(outdir):
+    dbs = sorted(glob.glob(os.path.join(outdir, "**", "*.db"), recursive=True), key=os.path.getsize)
+    return dbs[-1] if dbs else None
+
+
+def kernel_table(db):
+    """[(name, calls, total_us, avg_us)] sorted by total time (= rocprofv3 --stats' kernel table)."""
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, total_calls, total_duration, average from top_kernels"))
+    c.close()
+    return [(n, int(k), float(t), float(a)) for n, k, t, a in rows]
+
+
+def per_class(table, n_passes):
+    """{class: {launches_per_step, time_per_step_ms, avg_launch_us}} from a kernel table that covers n_passes model passes."""
+    out = {}
+    for name, calls, total_us, _ in table:
+        d = out.setdefault(classify(name), {"calls": 0, "total_us": 0.0})
+        d["calls"] += calls
+        d["total_us"] += total_us
+    res = {}
+    for cls, d in out.items():
+        res[cls] = {"launches_per_step": round(d["calls"] / n_passes, 1),
+                    "time_per_step_ms": round(d["total_us"] / n_passes / 1e3, 3),
+                    "avg_launch_us": round(d["total_us"] / max(d["calls"], 1), 2)}
+    return res
+
+
+def format_table(table, n_passes, header="", top=60):
+    tot = sum(t for _, _, t, _ in table)
+    lines = [header.rstrip()] if header else []
+    lines.append(f"{'kernel':90s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>9s} {'%':>6s} {'ms/step':>8s}")
+    for name, calls, total, avg in table[:top]:
+        lines.append(f"{name[:90]:90s} {calls:6d} {total / 1e3:10.3f} {avg:9.1f} {100 * total / tot:6.2f} {total / 1e3 / n_passes:8.3f}")
+    lines.append(f"{'TOTAL (' + str(n_passes) + ' model passes)':90s} {sum(c for _, c, _, _ in table):6d} {tot / 1e3:10.3f} {'':9s} {'':6s} {tot / 1e3 / n_passes:8.3f}")
+    return "\n".join(lines) + "\n"
+
+
+def pmc_sum(outdir, counter, pats):
+    """(sum of `counter` over the dispatches whose kernel name contains one of pats, number of such dispatches)"""
+    s, n = 0.0, 0
+    for path in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and any(p in r["Kernel_Name"] for p in pats):
+                s += float(r["Counter_Value"])
+                n += 1
+    return s, n
+
+
+def measure(child_argv, n_passes, pmc_argv=None, keep_dir=None, timeout=300):
+    """Kernel-trace child running `child_argv` (n_passes model passes) + two PMC children running `pmc_argv` (None: no
+    traffic measurement).  Returns dict(classes=..., table=..., traffic=..., notes=[...])."""
+    notes = []
+    base = keep_dir or tempfile.mkdtemp(prefix="segclip_rl_")
+    os.makedirs(base, exist_ok=True)
+    tdir = os.path.join(base, "trace")
+    rc, out, err = run_child(child_argv, tdir, None, timeout)
+    db = find_db(tdir)
+    if rc != 0 or db is None:
+        raise RuntimeError(f"rocprofv3 kernel-trace child failed (rc={rc}): {err[-400:]}")
+    table = kernel_table(db)
+    res = {"classes": per_class(table, n_passes), "table": table, "child_stdout": out, "traffic": None, "notes": notes}
+    if pmc_argv:
+        try:
+            pats = dict(CLASSES)["gemm_bf16"]
+            vals = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                pdir = os.path.join(base, "pmc_" + counter)
+                rc, _, err = run_child(pmc_argv, pdir, counter, timeout)
+                vals[counter] = pmc_sum(pdir, counter, pats)
+                if rc != 0 or vals[counter][1] == 0:
+                    raise RuntimeError(f"--pmc {counter} child: rc={rc}, {vals[counter][1]} GEMM dispatches: {err[-300:]}")
+            (f, nf), (w, nw) = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+            # KiB units; FETCH_SIZE doubled: gfx950 reports half of the bytes of wide coalesced streaming reads
+            res["traffic"] = {"hbm_bytes_per_launch": round((2 * f * 1024) / nf + (w * 1024) / nw),
+                              "fetch_bytes_per_launch_corrected": round(2 * f * 1024 / nf),
+                              "write_bytes_per_launch": round(w * 1024 / nw), "launches": nf,
+                              "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate counters-only child "
+                                        "runs of this command; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950)"}
+        except Exception as e:  # PMC passes are best effort: the trace numbers stand on their own
+            notes.append(f"traffic not measured: {e}")
+    if keep_dir is None:
+        shutil.rmtree(base, ignore_errors=True)
+    return res
