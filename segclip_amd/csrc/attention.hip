@@ -208,6 +208,7 @@ struct BwdArgs {
   float scale; int causal;
   const int* klen;     // nullable: valid keys per sample (fused kernel only)
   float* colsum_part;  // nullable: [B][3][H*hd] token sums of dQ | dK | dV (the in_proj bias gradient, per sample)
+  int abl;             // experiments (SEGCLIP_ATTN_ABL): 0 = the kernel; see attention_sp.inc
 };
 
 constexpr int TMAX = 256;
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
   }
 }
 
+#include "attention_sp.inc"
 #include "attention_stream.inc"
 #include "attention_fp8.inc"
 
@@ -634,6 +636,8 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.scale = d->scale; a.causal = d->causal;
     a.colsum_part = (float*)d->colsum_part;
     a.klen = (const int*)d->klen;
+    static const int abl_env = [] { const char* e = getenv("SEGCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    a.abl = abl_env;
     if (d->Tq > TMAX || d->Tk > TMAX) {
       SEGCLIP_REQUIRE(d->klen == nullptr, "attn_bwd bf16: klen needs sequences of at most %d tokens", TMAX);
       // long sequences: two streaming launches (dK,dV | dQ), 8 owned tiles per workgroup
@@ -659,6 +663,27 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
       return 0;
     }
     const int tiles = (int)cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32);
+    // self-attention: the single-pass kernel (attention_sp.inc), one wave per key tile.  SEGCLIP_ATTN_BWD_SP=0 falls back
+    // to the two-pass kernel (benchmarking); cross-attention (Tq != Tk) always takes the two-pass kernel.
+    static const int use_sp = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_SP"); return e ? atoi(e) : 1; }();
+    if (use_sp && d->Tq == d->Tk) {
+      const size_t lds_sp = bwd_sp_lds_bytes(tiles * 32);
+      static bool sp_attr_set = false;
+      if (!sp_attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_bf16_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_sp_lds_bytes(TMAX));
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_bf16_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_sp_lds_bytes(TMAX));
+        SEGCLIP_REQUIRE(e == hipSuccess && e2 == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        sp_attr_set = true;
+      }
+      if (d->causal || d->klen)
+        hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<true>, dim3((unsigned)(d->B * d->H)), dim3(tiles * 64), lds_sp, stream, a);
+      else
+        hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<false>, dim3((unsigned)(d->B * d->H)), dim3(tiles * 64), lds_sp, stream, a);
+      SEGCLIP_CHECK_LAUNCH("attn_bwd_sp_bf16");
+      return 0;
+    }
     // 4 waves per workgroup (each wave walks over 1-2 tiles): two such workgroups fit the registers (2 waves per SIMD
     // at ~215 VGPRs) and the LDS of a CU, so their load / MFMA / store phases interleave.  SEGCLIP_ATTN_BWD_WAVES
     // overrides (benchmarking).

@@ -109,7 +109,7 @@ def measure(child_argv, n_passes, pmc_argv=None, keep_dir=None, timeout=300):
     """Kernel-trace child running `child_argv` (n_passes model passes) + two PMC children running `pmc_argv` (None: no
     traffic measurement).  Returns dict(classes=..., table=..., traffic=..., notes=[...])."""
     notes = []
-    base = keep_dir or tempfile.mkdtemp(prefix="segclip_rl_")
+    base = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="segclip_rl_")   # the children run in /tmp
     os.makedirs(base, exist_ok=True)
     tdir = os.path.join(base, "trace")
     rc, out, err = run_child(child_argv, tdir, None, timeout)
