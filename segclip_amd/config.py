@@ -13,6 +13,10 @@ cross_mode    : "t18"      torch-1.8 key-buffer reinterpretation of CrossAttenti
 overlap_wgrad : weight-gradient GEMMs of a block on a second HIP stream; measured SLOWER (64.4 vs 59.5 ms/step:
                 two 139-KiB-LDS GEMMs cannot share a CU and the interleaving delays the dgrad chain), kept off
 overlap_towers: enqueue the text tower on a second HIP stream (concurrent with the vision tower)
+text_after_blocks : with overlap_towers: the text tower is enqueued after this many vision blocks (host launch order;
+                0 = before the vision tower).  The host needs ~3 ms to enqueue the text tower: queued first, the vision
+                stream idles that long at the start of every step, and - autograd replays the recording order backwards -
+                again ~6 ms at the end of the backward pass (tools/stream_gaps.py)
 trust_weight_shadows : False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
                 True: only weights whose autograd version changed (set per model by train.prep_optimizer when the
                 fused optimizer maintains the bf16 copies itself)
@@ -33,7 +37,7 @@ import types
 import torch
 
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
-                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True)
+                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, text_after_blocks=4)
 _tls = threading.local()
 
 
@@ -88,6 +92,19 @@ def scope(**overrides):
         yield
     finally:
         stack.pop()
+
+
+def set_stack_hook(after_blocks, fn):
+    """One-shot hook for the NEXT fused residual stack of this thread (SegViT._run_blocks): the stack is cut after
+    `after_blocks` blocks and fn() runs between the two parts.  SegCLIP.forward uses it to enqueue the text tower (second
+    stream) once the first vision blocks are queued, so that neither stream waits for the host (see modeling.py)."""
+    _tls.stack_hook = (int(after_blocks), fn)
+
+
+def take_stack_hook():
+    h = getattr(_tls, "stack_hook", None)
+    _tls.stack_hook = None
+    return h
 
 
 @contextlib.contextmanager

@@ -145,19 +145,40 @@ class SegCLIP(SegCLIPPreTrainedModel):
         # The two towers are independent until the similarity: the text tower (small GEMMs that leave most CUs
         # idle) is enqueued on a second HIP stream so its kernels fill the gaps of the vision tower; autograd runs
         # each node's backward on the stream of its forward, so the overlap carries over to the backward pass.
+        # Host launch order matters as much as the streams: the host needs ~3 ms to enqueue the text tower.  Enqueued before
+        # the vision tower, the vision stream (the critical path) idles that long at the start of every step - and again
+        # at the END of the backward pass, because autograd replays the recording order backwards (vision backward first,
+        # then ~6 ms of text-backward launches during which the vision stream has nothing queued).  So the text tower is
+        # enqueued after the first config.text_after_blocks vision blocks: in both passes the vision stream then has
+        # several milliseconds of work queued while the host feeds the text stream (tools/stream_gaps.py).
         if config.overlap_towers:
             main = torch.cuda.current_stream()
             side = self._text_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
-        else:
-            sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
-        visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
-                                                                          return_hidden=True)
-        if config.overlap_towers:
+            ready = torch.cuda.Event()
+            ready.record(main)           # weight shadows / inputs are ready: the text stream need not wait for vision blocks
+            box = {}
+
+            def enqueue_text():
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    box["seq"] = self.clip.encode_text_eot(input_ids).unsqueeze(1)
+            k = int(config.text_after_blocks)
+            if k > 0:
+                config.set_stack_hook(k, enqueue_text)
+            else:
+                enqueue_text()
+            visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
+                                                                              return_hidden=True)
+            pending = config.take_stack_hook()      # a vision tower without a fused stack never ran the hook
+            if pending is not None:
+                pending[1]()
+            sequence_output = box["seq"]
             main.wait_stream(side)
             sequence_output.record_stream(main)
+        else:
+            sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
+            visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
+                                                                              return_hidden=True)
         self.last_mid_states = mid_states
         sim_matrix_t2v, sim_matrix_v2t = self._loose_similarity(sequence_output, visual_output)
         offset = sequence_output.size(0) * int(getattr(self.task_config, "rank", 0))

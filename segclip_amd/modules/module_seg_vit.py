@@ -244,13 +244,28 @@ class SegViT(nn.Module):
 
     @staticmethod
     def _run_blocks(seq, x):
-        """nn.Sequential of ResidualAttentionBlocks as ONE autograd node (ops.ResStackFn) when there are several."""
+        """nn.Sequential of ResidualAttentionBlocks as ONE autograd node (ops.ResStackFn) when there are several.
+        A pending config.set_stack_hook(k, fn) cuts the stack after k blocks and runs fn() in between."""
         blocks = list(seq) if isinstance(seq, nn.Sequential) else None
+        hook = config.take_stack_hook()
         if (config.fuse_res_stack and blocks and len(blocks) > 1
                 and all(isinstance(b, ResidualAttentionBlock) and not b.causal for b in blocks)):
             b0 = blocks[0]
-            return ops.res_stack(x.float(), [b.block_params() for b in blocks], b0.n_head, False, ops.ACT_QUICK_GELU,
-                                 b0.ln_1.eps, config.compute_dtype)
+
+            def stack(bs, t):
+                if len(bs) == 1:
+                    return bs[0](t)
+                return ops.res_stack(t.float(), [b.block_params() for b in bs], b0.n_head, False, ops.ACT_QUICK_GELU,
+                                     b0.ln_1.eps, config.compute_dtype)
+            if hook is not None and 0 < hook[0] < len(blocks):
+                x = stack(blocks[:hook[0]], x)
+                hook[1]()
+                return stack(blocks[hook[0]:], x)
+            if hook is not None:
+                hook[1]()
+            return stack(blocks, x)
+        if hook is not None:
+            hook[1]()
         return seq(x)
 
     def forward_patches(self, x_):

@@ -101,6 +101,8 @@ def _run(spec_name, B, seed, dtype, flags, mode="t18", keep_grads=False):
                    dim={n: p.dim() for n, p in model.named_parameters()})
         if keep_grads:
             out["grads"] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        if getattr(model, "last_mae", None) is not None:
+            out["ids_restore"] = model.last_mae[1].cpu()
         del model, loss
         torch.cuda.empty_cache()
         return out
@@ -143,10 +145,49 @@ def test_b256_bf16_against_exact_f32_mode():
     assert dlog <= 0.6, dlog                             # measured 0.22 (logits are x14.3-scaled cosines)
     assert agree >= 0.98, agree                          # measured 0.994
     assert 0.98 <= med <= 1.03, med                      # measured 1.006
+    # bounds ~3x the error measured on MI355X with the shipped default (bf16 residual-gradient chain ON; numbers in
+    # profiles/r03_accuracy_b256.txt: matrices cosine >= 0.8986, norm ratio 0.988-1.127; vectors cosine >= 0.70 - the
+    # two ln_x biases of the center stage - and ratio 0.75-1.31)
     for n in mats:
-        assert 0.6 <= ratios[n] <= 1.6 and cos[n] >= 0.5, (n, ratios[n], cos[n])
+        assert 0.85 <= ratios[n] <= 1.30 and cos[n] >= 0.85, (n, ratios[n], cos[n])
     for n in vecs:
-        assert 0.4 <= ratios[n] <= 2.5 and cos[n] >= 0.3, (n, ratios[n], cos[n])
+        assert 0.6 <= ratios[n] <= 1.6 and cos[n] >= 0.55, (n, ratios[n], cos[n])
+    # the chain itself: the same step with the fp32 residual gradient must give the same picture (measured: every cosine
+    # equal to 3 decimals; if the chain ever cost more than 2 points of cosine it would have to be switched off)
+    segclip_amd.config.bf16_resgrad = False
+    try:
+        b2 = _run("vitb16", 256, 3, torch.bfloat16, {}, "intended", keep_grads=True)
+    finally:
+        segclip_amd.config.bf16_resgrad = True
+    worst = 0.0
+    for n in ratios:
+        c2 = float((f["grads"][n].double() * b2["grads"][n].double()).sum()) / (f["gn"][n] * b2["gn"][n])
+        worst = max(worst, c2 - cos[n])
+    print(f"    bf16 residual-gradient chain: largest cosine loss against the fp32 residual gradient {worst:.4f}")
+    assert worst <= 0.02, worst
+
+
+def test_b256_full_loss_bf16_against_exact_f32_mode():
+    """BASELINE configs[3] size: full SegCLIP loss (contrastive + superpixel-KL + MAE) at B = 256, bf16 (shipped
+    defaults) against the exact-f32 mode: loss, logits, hard assignment and MAE index maps, every parameter gradient
+    by cosine and norm.  Measured on MI355X (profiles/r03_accuracy_b256.txt): d loss 2.6e-4, hard_idx agreement 0.9939,
+    ids_restore identical, matrices cosine >= 0.915 / ratio 0.989-1.10, vectors cosine >= 0.913 / ratio 0.975-1.14."""
+    f = _run("vitb16", 256, 3, torch.float32, FULL_FLAGS, "intended", keep_grads=True)
+    b = _run("vitb16", 256, 3, torch.bfloat16, FULL_FLAGS, "intended", keep_grads=True)
+    dl = abs(f["loss"] - b["loss"])
+    agree = float((f["hard_idx"] == b["hard_idx"]).float().mean())
+    assert set(f["gn"]) == set(b["gn"])
+    ratios = {n: b["gn"][n] / f["gn"][n] for n in f["gn"] if f["gn"][n] > 1e-6}
+    cos = {n: float((f["grads"][n].double() * b["grads"][n].double()).sum()) / (f["gn"][n] * b["gn"][n]) for n in ratios}
+    cm = min(ratios, key=lambda n: cos[n])
+    print(f"\n[B=256 full loss bf16 vs f32] loss {b['loss']:.5f} vs {f['loss']:.5f} (d {dl:.2e}); hard_idx agreement {agree:.4f}; "
+          f"worst cosine {cm} {cos[cm]:.4f}; norm ratio {min(ratios.values()):.4f} .. {max(ratios.values()):.4f}")
+    assert dl <= 1e-3, dl
+    assert agree >= 0.98, agree
+    assert torch.equal(f["ids_restore"], b["ids_restore"])      # the MAE shuffle is an integer function of the injected noise
+    for n in ratios:
+        lo, hi, cmin = (0.85, 1.30, 0.80) if b["dim"][n] >= 2 else (0.8, 1.4, 0.75)
+        assert lo <= ratios[n] <= hi and cos[n] >= cmin, (n, ratios[n], cos[n])
 
 
 def test_b4_bf16_grad_norms_against_reference_golden():
