@@ -586,7 +586,6 @@ def test_res_stack_bf16_chain_depth12_width768():
     the size of the error bf16 operands cause anyway (measured on MI355X, worst GEMM-weight gradient over the 12 blocks:
     chain vs fp32 residual gradient 9.0e-3, bf16 vs exact-f32 6.9e-3; input gradient 8.9e-3 / 4.5e-3); bounds = 3x."""
     # (the whole-model effect at B = 256 is pinned in tests/test_bench_size_gpu.py: no cosine moves by more than 0.002)
-    """"""
     import segclip_amd
     B, T, D, H, nblk = 2, 196, 768, 12, 12
     g = torch.Generator().manual_seed(11)
