@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   // oldest entries of the in-order VM queue: the first counted wait of the prologue covers them.  Measured on MI355X
   // (tools/bench_epi.py, M = 50176): SLOWER - out_proj +fp32 residual 89.8 -> 114.1 us, c_proj +residual 253 -> 268,
   // act' dgrad 326 -> 340: the epilogue is not waiting for the latency of these loads.
-  if (g.touch && g.splits == 1 && (g.mul_dact || g.residual) && n0 + BT <= g.N) {
+  if ((g.touch & 1) && g.splits == 1 && (g.mul_dact || g.residual) && n0 + BT <= g.N) {
     const int esz = g.mul_dact ? (g.c_dtype == SEGCLIP_BF16 ? 2 : 4) : (g.r_dtype == SEGCLIP_BF16 ? 2 : 4);
     const int64_t pitch = (g.mul_dact ? g.ldaux : g.ldr) * esz;
     const char* sp = g.mul_dact ? reinterpret_cast<const char*>(g.aux) + (coff + m0 * g.ldaux + n0) * esz
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
 
   // The first round of workgroups (one per CU) starts with a bounded, staggered delay so that the CUs do not all reach
   // their store phase at the same moment in every later round (kept from gemm_bf16_dma.hip, where it measured +5..10 %).
-  if (bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
+  if (!(g.touch & 2) && bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
     const long long t_tile = (long long)nk * 3000 + 20000;
     const long long unit = t_tile / 8 < 5000 ? t_tile / 8 : 5000;
     // tiles of one block row share their A rows through the XCD's L2: they get the SAME delay and stay in lockstep
@@ -427,7 +427,8 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   if ((a_ks ? 64 : 256) * (a_ks ? d->sak : d->sam) * 2 >= (int64_t)1 << 31) return false;
   if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
   static const int touch = [] { const char* e = getenv("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
-  g.touch = touch;
+  static const int stagger = [] { const char* e = getenv("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 1; }();
+  g.touch = (touch ? 1 : 0) | (stagger ? 0 : 2);   // bit 0: side-tile touch experiment, bit 1: no first-round stagger
   g.nbx = (int)cdiv(d->N, BT);
   g.nby = (int)cdiv(d->M, BT);
   g.splits = splits;

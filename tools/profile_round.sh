@@ -1,36 +1,33 @@
 #!/bin/bash
 # tools/profile_round.sh <tag>   (run on the GPU box; results under gpurun_out/<tag>/)
-# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> kernel_stats.txt
-# 2. PMC passes (separate runs, counters only) of ONE bench step     -> gemm traffic json (FETCH_SIZE / WRITE_SIZE)
-# 3. PMC passes of single GEMM shapes (MFMA busy, LDS conflicts, L2 hit rate) for the three operand layouts
-TAG=${1:-r02}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+# 1. the default bench command, with its own rocprofv3 children kept: bench line + kernel table (the SAME run) + live PMC traffic
+# 2. the bench configurations the docs quote (B=2048 strong-scaling base, full loss, --force-dist, ViT-L/14)
+# 3. PMC passes of single GEMM shapes (MFMA busy, LDS conflicts, L2 hit rate) for the three operand layouts, and of the
+#    attention kernels
+TAG=${1:-r03}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/bench_prof.err
-python tools/prof_summary.py $(ls $OUT/prof/*.db | head -1) 60 > $OUT/kernel_stats.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$c.log 2>&1
-done
-python tools/pmc_traffic.py $(ls $OUT/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1) $OUT/gemm_traffic.json > $OUT/gemm_traffic.log 2>&1
+F='^RCCL\|^HIP\|^ROCm\|Hostname\|Librccl\|amdgpu.ids\|socket.cpp\|ProcessGroupNCCL'
+SEGCLIP_BENCH_PROFILE_DIR=$OUT/rl timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
+cp $OUT/rl/kernel_stats.txt $OUT/kernel_stats.txt
+python tools/stream_gaps.py $(ls $OUT/rl/trace/*.db $OUT/rl/trace/*/*.db 2>/dev/null | head -1) 120 > $OUT/stream_gaps.txt 2>&1
+rm -rf $OUT/rl/trace $OUT/rl/pmc_*
+b() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "$name: $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$name.json) $(grep -o '"value": [0-9.]*' $OUT/bench_$name.json | head -1)"; }
+b gb2048 --no-cpu-baseline --no-traffic --global-batch 2048 --steps 5 --warmup 2
+b full_loss --no-cpu-baseline --no-traffic --full-loss
+b dist --no-cpu-baseline --no-roofline --force-dist
+b dist_bf16wire --no-cpu-baseline --no-roofline --force-dist --wire bf16
+b vitl14 --no-cpu-baseline --no-traffic --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
+b vitl14_fp8 --no-cpu-baseline --no-roofline --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 on
+for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --batch $bsz; done
+timeout 300 python tools/bench_hbm.py 2>&1 | grep -v "$F" > $OUT/hbm_kernels.txt
+timeout 300 python tools/bench_gemm.py 2>&1 | grep -v "$F" > $OUT/gemm_shapes.txt
+timeout 300 python tools/bench_gemm.py 19712 text 2>&1 | grep -v "$F" >> $OUT/gemm_shapes.txt
+timeout 300 python tools/bench_epi.py 2>&1 | grep -v "$F" > $OUT/gemm_epilogues.txt
+timeout 200 python tools/bench_attn.py 2>&1 | grep -v "$F" > $OUT/attn.txt
 for spec in "50176 768 3072 nt" "50176 3072 768 dgrad" "50176 2304 768 wgrad"; do
   set -- $spec
   timeout 600 bash tools/pmc_gemm.sh $1 $2 $3 $4 $OUT/pmc_gemm_$4 > $OUT/pmc_gemm_$4.txt 2>&1
 done
-python - "$OUT" <<'PY'
-import csv, glob, sys, collections, re
-out = sys.argv[1]
-for mode in ("nt", "dgrad", "wgrad"):
-    tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-    for f in glob.glob(f"{out}/pmc_gemm_{mode}/*/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            m = re.search(r"(gemm_bf16\w*|splitk\w*)", r["Kernel_Name"])
-            if not m: continue
-            k = m.group(1)
-            tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
-            if r["Counter_Name"] in ("SQ_WAVE_CYCLES", "TCC_HIT_sum", "FETCH_SIZE"):
-                tot[k]["_ns_" + r["Counter_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); cnt[k]["_ns_" + r["Counter_Name"]] += 1
-    with open(f"{out}/pmc_gemm_{mode}_summary.txt", "w") as fo:
-        for k in tot:
-            fo.write(f"== {mode}: {k}\n")
-            for c in sorted(tot[k]): fo.write("  %-34s per launch %16.0f (%d launches)\n" % (c, tot[k][c] / cnt[k][c], cnt[k][c]))
-PY
-cat $OUT/kernel_stats.txt | head -30 | cut -c1-140; cat $OUT/gemm_traffic.log | tail -2; cat $OUT/pmc_gemm_*_summary.txt | head -80
+timeout 600 bash tools/pmc_attn.sh $OUT/pmc_attn 256 196 12 0 > $OUT/pmc_attn.txt 2>&1
+rm -rf $OUT/pmc_gemm_*/*/ $OUT/pmc_attn/*/ 2>/dev/null
+head -30 $OUT/kernel_stats.txt | cut -c1-150; cat $OUT/stream_gaps.txt | head -5; tail -c 600 $OUT/bench_line.json
