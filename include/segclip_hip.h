@@ -81,10 +81,48 @@ typedef struct segclip_gemm_desc {
                        Needs colsum_ws = (M/64)*N floats, M % 256 == 0, N % 256 == 0 and the LDS-DMA bf16 path;
                        otherwise segclip_gemm returns SEGCLIP_ERR_UNSUPPORTED without launching. */
   float* colsum_ws;
+  int32_t flags;    /* SEGCLIP_GEMM_DEFER_*: leave the trailing reduction launches to the caller (segclip_reduce_multi):
+                       the split-K slabs stay in ws, the column-sum partials in colsum_ws */
+  int32_t reserved2;
 } segclip_gemm_desc;
 
+#define SEGCLIP_GEMM_DEFER_SPLITK 1 /* do not launch the split-K combine: C is NOT written; combine ws later */
+#define SEGCLIP_GEMM_DEFER_COLSUM 2 /* do not launch the column-sum reduction of colsum_ws ((M/64) x N partials) */
+
 size_t segclip_gemm_ws_bytes(const segclip_gemm_desc* d);
+/* number of K splits segclip_gemm(d) uses with the ws / ws_bytes given in d: ws then holds that many (nb1*nb2*M*N) fp32
+ * slabs before the combine (SEGCLIP_GEMM_DEFER_SPLITK leaves them there); 1 = no split-K */
+int segclip_gemm_splits(const segclip_gemm_desc* d);
 int segclip_gemm(const segclip_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Deferred reductions, many per launch.  The backward of a residual block ends in ~8 small reductions (4 split-K
+ * combines of the weight gradients, the dgamma|dbeta|column-sum partials of 2 LayerNorm backwards, fused bias-gradient
+ * column sums): their producers can leave the partials in their workspaces (SEGCLIP_GEMM_DEFER_*,
+ * segclip_layernorm_bwd with dgamma == NULL) and the caller combines them with ONE launch per kind.
+ *   kind SEGCLIP_REDUCE_SLABS: out[i] = scale * sum_s src[s*width + i], i < width (width % 4 == 0; fp32 or bf16 out)
+ *   kind SEGCLIP_REDUCE_ROWS : out_k[c] = sum_r src[r*ld + k*seg + c] for k < nseg, c < seg (fp32 out, seg % 4 == 0):
+ *                              column sums of a (rows x nseg*seg) partial matrix, split into up to 3 output arrays
+ * Deterministic (fixed summation order), n <= SEGCLIP_REDUCE_MAX entries per call, all of one kind.
+ * Replaces nothing in the reference (torch sums these inside its autograd kernels); it is the second stage of
+ * modules/module_clip_util.py:126-132 (LayerNorm backward) and of every nn.Linear weight / bias gradient.
+ * ------------------------------------------------------------------------------------------ */
+#define SEGCLIP_REDUCE_SLABS 0
+#define SEGCLIP_REDUCE_ROWS 1
+#define SEGCLIP_REDUCE_MAX 16
+typedef struct segclip_reduce_entry {
+  const float* src;
+  void* out0;
+  float* out1;
+  float* out2;
+  int64_t rows;   /* SLABS: number of slabs; ROWS: number of partial rows */
+  int64_t width;  /* SLABS: elements per slab; ROWS: nseg * seg */
+  int64_t ld;     /* ROWS: leading dimension of src (floats) */
+  int64_t seg;    /* ROWS: columns per output array */
+  float scale;    /* SLABS only */
+  int32_t out_dtype; /* SLABS: SEGCLIP_F32 / SEGCLIP_BF16 */
+} segclip_reduce_entry;
+int segclip_reduce_multi(const segclip_reduce_entry* entries, int n, int kind, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last axis (fp32 statistics).  modules/module_clip_util.py:126-132,
@@ -94,6 +132,8 @@ int segclip_gemm(const segclip_gemm_desc* d, void* stream);
  *      dres_colsum (optional, needs dres): column sums of dres = the bias gradient of the Linear whose
  *      output gradient dres is (fused here because this kernel streams dres anyway).
  * ws: segclip_layernorm_bwd_ws_bytes(rows, cols) bytes of scratch.
+ * dgamma == NULL: the final reduction is left to the caller - ws then holds segclip_layernorm_bwd_ws_bytes / (3*cols*4)
+ *      partial rows of [dgamma | dbeta | dres column sums] (3*cols floats each), see segclip_reduce_multi.
  * ------------------------------------------------------------------------------------------ */
 int segclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                           float* rstd, int64_t rows, int64_t cols, float eps, int x_dtype, int y_dtype,

@@ -11,6 +11,8 @@ import torch
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
+GEMM_DEFER_SPLITK, GEMM_DEFER_COLSUM = 1, 2
+REDUCE_SLABS, REDUCE_ROWS, REDUCE_MAX = 0, 1, 16
 ATTN_FP8 = 1
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsegclip_hip.so")
@@ -27,7 +29,12 @@ class GemmDesc(C.Structure):
                 ("bsR1", i64), ("bsR2", i64),
                 ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("r_dtype", i32),
                 ("act", i32), ("mul_dact", i32), ("alpha", f32), ("aux_kind", i32),
-                ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp)]
+                ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp), ("flags", i32), ("reserved2", i32)]
+
+
+class ReduceEntry(C.Structure):
+    _fields_ = [("src", vp), ("out0", vp), ("out1", vp), ("out2", vp), ("rows", i64), ("width", i64), ("ld", i64), ("seg", i64),
+                ("scale", f32), ("out_dtype", i32)]
 
 
 class TrainCtrl(C.Structure):
@@ -62,7 +69,9 @@ SIGNATURES = {
     "segclip_version": (C.c_int, []),
     "segclip_last_error_string": (C.c_char_p, []),
     "segclip_gemm_ws_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "segclip_gemm_splits": (C.c_int, [C.POINTER(GemmDesc)]),
     "segclip_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "segclip_reduce_multi": (C.c_int, [C.POINTER(ReduceEntry), C.c_int, C.c_int, vp]),
     "segclip_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),
     "segclip_layernorm_bwd_ws_bytes": (C.c_size_t, [i64, i64]),
     "segclip_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),

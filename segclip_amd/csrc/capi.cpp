@@ -7,6 +7,7 @@
 int segclip_gemm_f32_launch(const segclip_gemm_desc* d, hipStream_t stream);
 int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream);
 size_t segclip_gemm_bf16_ws_bytes(const segclip_gemm_desc* d);
+int segclip_gemm_bf16_splits(const segclip_gemm_desc* d);
 
 static thread_local char g_err[512] = "";
 
@@ -23,6 +24,11 @@ extern "C" const char* segclip_last_error_string(void) { return g_err; }
 extern "C" size_t segclip_gemm_ws_bytes(const segclip_gemm_desc* d) {
   if (d->b_dtype == SEGCLIP_BF16) return segclip_gemm_bf16_ws_bytes(d);
   return 0;
+}
+
+extern "C" int segclip_gemm_splits(const segclip_gemm_desc* d) {
+  if (d->b_dtype == SEGCLIP_BF16 && !(d->a_dtype == SEGCLIP_F32 && d->b_dtype == SEGCLIP_F32)) return segclip_gemm_bf16_splits(d);
+  return 1;
 }
 
 extern "C" int segclip_gemm(const segclip_gemm_desc* d, void* stream) {

@@ -423,6 +423,15 @@ size_t segclip_gemm_bf16_ws_bytes(const segclip_gemm_desc* d) {
   return (size_t)s * nb * d->M * d->N * sizeof(float);
 }
 
+// number of K splits segclip_gemm_bf16_launch() will use for this descriptor (1 = no split-K, nothing in ws)
+int segclip_gemm_bf16_splits(const segclip_gemm_desc* d) {
+  int splits = choose_splits(d);
+  if (splits > 1 && (d->ws == nullptr || (size_t)d->ws_bytes < segclip_gemm_bf16_ws_bytes(d))) splits = 1;
+  if (splits <= 1) return 1;
+  const int64_t kper = cdiv(cdiv(d->K, BK), splits) * BK;
+  return (int)cdiv(d->K, kper);
+}
+
 int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
   SEGCLIP_REQUIRE(!a_ks || d->sam == 1, "gemm_bf16: A needs unit stride along k or m (sam=%lld sak=%lld)",
@@ -481,11 +490,11 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     else segclip_gb_launch_kf(a_f32, fast, grid, stream, &g);
   }
   SEGCLIP_CHECK_LAUNCH("gemm_bf16");
-  if (d->colsum) {
+  if (d->colsum && !(d->flags & SEGCLIP_GEMM_DEFER_COLSUM)) {
     launch_reduce_rows((const float*)d->colsum_ws, d->M / 64, d->N, d->N, d->colsum, nullptr, nullptr, d->N, stream);
     SEGCLIP_CHECK_LAUNCH("gemm_colsum_reduce");
   }
-  if (g.splits > 1) {
+  if (g.splits > 1 && !(d->flags & SEGCLIP_GEMM_DEFER_SPLITK)) {
     const int64_t total = nb * d->M * d->N;
     const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
     const int64_t cal = d->c_dtype == SEGCLIP_BF16 ? 7 : 15;

@@ -279,8 +279,10 @@ extern "C" int segclip_layernorm_bwd(const void* dy, const void* x, const float*
 #undef LNB4
 #undef LNBK
   SEGCLIP_CHECK_LAUNCH("layernorm_bwd");
-  launch_reduce_rows((const float*)ws, nb, (dres && dres_colsum ? 3 : 2) * cols, 3 * cols, dgamma, dbeta,
-                     dres ? dres_colsum : nullptr, cols, (hipStream_t)stream);
-  SEGCLIP_CHECK_LAUNCH("layernorm_bwd_reduce");
+  if (dgamma != nullptr) {   // dgamma == NULL: the caller combines the nb partial rows of ws itself (segclip_reduce_multi)
+    launch_reduce_rows((const float*)ws, nb, (dres && dres_colsum ? 3 : 2) * cols, 3 * cols, dgamma, dbeta,
+                       dres ? dres_colsum : nullptr, cols, (hipStream_t)stream);
+    SEGCLIP_CHECK_LAUNCH("layernorm_bwd_reduce");
+  }
   return 0;
 }

@@ -730,3 +730,120 @@ extern "C" int segclip_interp_bicubic(const float* src, float* dst, int64_t n_in
   SEGCLIP_CHECK_LAUNCH("interp_bicubic");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// segclip_reduce_multi: up to 16 deferred reductions of one kind in ONE launch (the entry table travels in the kernel
+// arguments).  Workgroup b serves entry e with start[e] <= b < start[e+1].
+namespace {
+struct ReduceLaunch {
+  segclip_reduce_entry e[SEGCLIP_REDUCE_MAX];
+  int start[SEGCLIP_REDUCE_MAX + 1];
+  int n;
+};
+
+// SLABS: out[i] = scale * sum_s src[s*width + i]; 256 threads x float4 per workgroup
+__global__ __launch_bounds__(256) void reduce_multi_slabs_kernel(ReduceLaunch L) {
+  int ei = 0;
+  while (ei + 1 < L.n && (int)blockIdx.x >= L.start[ei + 1]) ++ei;
+  const segclip_reduce_entry& E = L.e[ei];
+  const int64_t total4 = E.width >> 2;
+  const int64_t i = (int64_t)((int)blockIdx.x - L.start[ei]) * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(E.src) + i;
+  const int splits = (int)E.rows;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+#pragma unroll 1
+  for (; s + 8 <= splits; s += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(s + u) * total4];
+    v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  }
+  if (s + 4 <= splits) {
+    const f32x4 a = p[(int64_t)s * total4], b = p[(int64_t)(s + 1) * total4], c = p[(int64_t)(s + 2) * total4],
+                d = p[(int64_t)(s + 3) * total4];
+    v += (a + b) + (c + d);
+    s += 4;
+  }
+  for (; s < splits; ++s) v += p[(int64_t)s * total4];
+  v *= E.scale;
+  if (E.out_dtype == SEGCLIP_BF16) reinterpret_cast<u32x2*>(E.out0)[i] = u32x2{pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+  else reinterpret_cast<f32x4*>(E.out0)[i] = v;
+}
+
+// ROWS: column sums of a (rows x width) partial matrix; workgroup = 16 columns (4 lanes x float4) x 64 row lanes
+// (same arithmetic and summation order as reduce_rows_kernel)
+__global__ __launch_bounds__(256) void reduce_multi_rows_kernel(ReduceLaunch L) {
+  __shared__ f32x4 red[4][4];
+  int ei = 0;
+  while (ei + 1 < L.n && (int)blockIdx.x >= L.start[ei + 1]) ++ei;
+  const segclip_reduce_entry& E = L.e[ei];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int64_t c = ((int64_t)((int)blockIdx.x - L.start[ei]) * 4 + cl) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < E.width) {
+    const float* p = E.src + c;
+    int64_t r = rl;
+#pragma unroll 1
+    for (; r + 7 * 64 < E.rows; r += 8 * 64) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (r + u * 64) * E.ld);
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < E.rows; r += 64) s += *reinterpret_cast<const f32x4*>(p + r * E.ld);
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    s.x += __shfl_xor(s.x, o, 64);
+    s.y += __shfl_xor(s.y, o, 64);
+    s.z += __shfl_xor(s.z, o, 64);
+    s.w += __shfl_xor(s.w, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 4) red[w][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 4 && c < E.width) {
+    const f32x4 t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    const int64_t k = c / E.seg;                   // seg % 4 == 0: the four columns share a segment
+    float* o = k == 0 ? (float*)E.out0 : (k == 1 ? E.out1 : E.out2);
+    if (o) *reinterpret_cast<f32x4*>(o + (c - k * E.seg)) = t;
+  }
+}
+}  // namespace
+
+extern "C" int segclip_reduce_multi(const segclip_reduce_entry* entries, int n, int kind, void* stream) {
+  SEGCLIP_REQUIRE(n >= 0 && n <= SEGCLIP_REDUCE_MAX, "reduce_multi: n=%d entries (max %d)", n, SEGCLIP_REDUCE_MAX);
+  SEGCLIP_REQUIRE(kind == SEGCLIP_REDUCE_SLABS || kind == SEGCLIP_REDUCE_ROWS, "reduce_multi: unknown kind %d", kind);
+  if (n == 0) return 0;
+  ReduceLaunch L;
+  int64_t blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const segclip_reduce_entry& e = entries[i];
+    SEGCLIP_REQUIRE(e.src && e.out0 && e.rows >= 1 && e.width >= 4 && e.width % 4 == 0,
+                    "reduce_multi: entry %d: src/out0 null, rows < 1 or width %% 4 != 0", i);
+    SEGCLIP_REQUIRE((reinterpret_cast<uintptr_t>(e.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(e.out0) & 15) == 0,
+                    "reduce_multi: entry %d: src / out0 must be 16-byte aligned", i);
+    if (kind == SEGCLIP_REDUCE_ROWS) {
+      SEGCLIP_REQUIRE(e.seg >= 4 && e.seg % 4 == 0 && e.ld % 4 == 0 && e.width <= 3 * e.seg && e.width % e.seg == 0,
+                      "reduce_multi: entry %d: seg / ld must be multiples of 4, width = 1..3 segments", i);
+      SEGCLIP_REQUIRE((!e.out1 || (reinterpret_cast<uintptr_t>(e.out1) & 15) == 0) &&
+                      (!e.out2 || (reinterpret_cast<uintptr_t>(e.out2) & 15) == 0), "reduce_multi: entry %d: unaligned out", i);
+    } else {
+      SEGCLIP_REQUIRE(e.out_dtype == SEGCLIP_F32 || e.out_dtype == SEGCLIP_BF16, "reduce_multi: entry %d: bad out dtype", i);
+    }
+    L.e[i] = e;
+    L.start[i] = (int)blocks;
+    blocks += kind == SEGCLIP_REDUCE_SLABS ? cdiv(e.width / 4, 256) : cdiv(e.width, 16);
+    SEGCLIP_REQUIRE(blocks < ((int64_t)1 << 31), "reduce_multi: too many workgroups");
+  }
+  L.start[n] = (int)blocks;
+  L.n = n;
+  if (kind == SEGCLIP_REDUCE_SLABS)
+    hipLaunchKernelGGL(reduce_multi_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, L);
+  else
+    hipLaunchKernelGGL(reduce_multi_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, L);
+  SEGCLIP_CHECK_LAUNCH("reduce_multi");
+  return 0;
+}

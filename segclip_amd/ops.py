@@ -61,6 +61,39 @@ class _OpCount:
         cls.records.append((kind, float(flops), float(nbytes)))
 
 
+class ReduceQueue:
+    """Deferred trailing reductions of a group of launches (one residual block's backward): the split-K combines of the
+    weight gradients and the row reductions behind the LayerNorm backwards / fused bias-gradient column sums are left in
+    their workspaces and combined by ONE launch per kind (segclip_reduce_multi) when the group is flushed - 2 launches
+    instead of ~8 per block.  The workspaces are kept alive until the flush has been enqueued."""
+
+    def __init__(self):
+        self.slabs, self.rows, self.keep = [], [], []
+
+    def add_slabs(self, ws, out, n_slabs, width, scale):
+        e = L.ReduceEntry()
+        e.src, e.out0, e.rows, e.width, e.scale, e.out_dtype = L.ptr(ws), L.ptr(out), n_slabs, width, float(scale), L.dt(out)
+        self.slabs.append(e)
+        self.keep.extend((ws, out))
+
+    def add_rows(self, part, rows, width, ld, outs, seg):
+        e = L.ReduceEntry()
+        e.src, e.rows, e.width, e.ld, e.seg = L.ptr(part), rows, width, ld, seg
+        e.out0, e.out1, e.out2 = (L.ptr(o) for o in (tuple(outs) + (None, None))[:3])
+        self.rows.append(e)
+        self.keep.append(part)
+        self.keep.extend(o for o in outs if o is not None)
+
+    def flush(self):
+        lib = L.load()
+        for kind, ents in ((L.REDUCE_SLABS, self.slabs), (L.REDUCE_ROWS, self.rows)):
+            for i in range(0, len(ents), L.REDUCE_MAX):
+                chunk = ents[i:i + L.REDUCE_MAX]
+                arr = (L.ReduceEntry * len(chunk))(*chunk)
+                L.check(lib.segclip_reduce_multi(arr, len(chunk), kind, L.stream()), "reduce_multi")
+        self.slabs, self.rows, self.keep = [], [], []
+
+
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -77,7 +110,7 @@ def _off(t, off):
 # ------------------------------------------------------------------------------------------------
 def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=None, residual=None, ldr=0,
            r_off=0, aux=None, ldaux=0, act=ACT_NONE, mul_dact=False, alpha=1.0, nb1=1, nb2=1, bsA=(0, 0),
-           bsB=(0, 0), bsC=(0, 0), bsR=None, colsum=None, aux_kind=0):
+           bsB=(0, 0), bsC=(0, 0), bsR=None, colsum=None, aux_kind=0, defer=None):
     """C(m,n) = epi(alpha * sum_k A(m,k) B(n,k)); sa = (sam, sak), sb = (sbn, sbk) element strides."""
     lib = L.load()
     L.require_cuda(A, B, Cc)
@@ -100,14 +133,26 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     if aux is not None and aux.dtype != Cc.dtype:
         raise TypeError("gemm: aux dtype must equal output dtype")
     d.act, d.mul_dact, d.alpha, d.aux_kind = act, int(mul_dact), float(alpha), int(aux_kind)
+    flags = 0
     if colsum is not None:
         csws = torch.empty((max(M // 64, 1), N), dtype=torch.float32, device=A.device)
         d.colsum, d.colsum_ws = L.ptr(colsum), L.ptr(csws)
+        if defer is not None:
+            flags |= L.GEMM_DEFER_COLSUM
+            defer.add_rows(csws, M // 64, N, N, (colsum,), N)
     ws = None
     nbytes = lib.segclip_gemm_ws_bytes(C.byref(d))
     if nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = L.ptr(ws), nbytes
+        # split-K: the combine can be deferred when C is one contiguous (M, N) array
+        if (defer is not None and nb1 * nb2 == 1 and ldc == N and c_off == 0 and Cc.is_contiguous()
+                and (M * N) % 4 == 0 and Cc.data_ptr() % 16 == 0):
+            ns = lib.segclip_gemm_splits(C.byref(d))
+            if ns > 1:
+                flags |= L.GEMM_DEFER_SPLITK
+                defer.add_slabs(ws, Cc, ns, M * N, alpha)
+    d.flags = flags
     if _OpCount.enabled:
         nz = nb1 * nb2
         _OpCount.add("gemm_bf16" if B.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * nz,
@@ -163,7 +208,7 @@ def fused_colsum_ok(M, N, K, dtype):
     return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0
 
 
-def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None, aux_kind=0):
+def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None, aux_kind=0, defer=None):
     """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)
     want_colsum: also return the column sums of dx (= bias gradient of the Linear that produced the
     pre-activation), fused into the GEMM epilogue when the shape allows, else by the colsum kernel."""
@@ -177,7 +222,7 @@ def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=Fa
     if want_colsum and fused_colsum_ok(M, K, N, out_dtype) and dy.dtype == torch.bfloat16:
         cs = colsum_out if colsum_out is not None else _empty((K,), torch.float32, dy)
     p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None, colsum=cs,
-           aux_kind=aux_kind)
+           aux_kind=aux_kind, defer=defer)
     if want_colsum:
         return dx, (cs if cs is not None else p_colsum(dx, out=colsum_out))
     return dx
@@ -198,7 +243,7 @@ def _slot_out(slot, shape):
     return out
 
 
-def p_wgrad(dy, x, w_kn=False, out=None):
+def p_wgrad(dy, x, w_kn=False, out=None, defer=None):
     """dw = dy^T x (N,K) fp32  [or x^T dy (K,N) when w_kn];  dy (M,N), x (M,K).  `out`: preallocated fp32 result."""
     M, N = dy.shape
     K = x.shape[1]
@@ -208,12 +253,12 @@ def p_wgrad(dy, x, w_kn=False, out=None):
         dw = out if out is not None else _empty((K, N), torch.float32, dy)
         if dy.dtype == torch.float32 and x.dtype != torch.float32:
             dy = p_cast(dy, x.dtype)
-        p_gemm(x, dy, dw, K, N, M, (1, _ld(x)), (1, _ld(dy)), N)
+        p_gemm(x, dy, dw, K, N, M, (1, _ld(x)), (1, _ld(dy)), N, defer=defer)
         return dw
     if x.dtype == torch.float32 and dy.dtype != torch.float32:
         x = p_cast(x, dy.dtype)  # only the A operand may be fp32 on the bf16 path
     dw = out if out is not None else _empty((N, K), torch.float32, dy)
-    p_gemm(dy, x, dw, N, K, M, (1, _ld(dy)), (1, _ld(x)), K)
+    p_gemm(dy, x, dw, N, K, M, (1, _ld(dy)), (1, _ld(x)), K, defer=defer)
     return dw
 
 
@@ -240,7 +285,8 @@ def p_ln_fwd(x, w, b, eps, out_dtype):
     return y, mean, rstd
 
 
-def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, want_dres_colsum=False, outs=(None, None, None)):
+def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, want_dres_colsum=False, outs=(None, None, None),
+             defer=None):
     """-> dx, dgamma, dbeta [, dx_bf16] [, colsum(dres)];  outs = preallocated (dgamma, dbeta, colsum) buffers or None"""
     lib = L.load()
     dy = dy.contiguous()
@@ -260,10 +306,14 @@ def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, wa
     if _OpCount.enabled:
         _OpCount.add("ln_bwd", 0, rows * cols * (dy.element_size() + x.element_size() + dx.element_size() * (2 if dres is not None else 1)
                                                  + (2 if want_bf16 else 0)))
-    ws = torch.empty(max(lib.segclip_layernorm_bwd_ws_bytes(rows, cols), 4), dtype=torch.uint8, device=x.device)
+    wsb = lib.segclip_layernorm_bwd_ws_bytes(rows, cols)
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=x.device)
+    deferred = defer is not None and rows > 0 and all(t.data_ptr() % 16 == 0 for t in (dw, db) + ((dsum,) if dsum is not None else ()))
     L.check(lib.segclip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
-                                      L.ptr(dx16), L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws), rows, cols, L.dt(dy),
-                                      L.dt(x), L.dt(dx), L.stream()), "layernorm_bwd")
+                                      L.ptr(dx16), None if deferred else L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws), rows, cols,
+                                      L.dt(dy), L.dt(x), L.dt(dx), L.stream()), "layernorm_bwd")
+    if deferred:   # ws = [blocks][dgamma | dbeta | colsum(dres)] partial rows
+        defer.add_rows(ws, wsb // (3 * cols * 4), (3 if dsum is not None else 2) * cols, 3 * cols, (dw, db, dsum), cols)
     out = [dx, dw, db]
     if want_bf16:
         out.append(dx16)
@@ -609,22 +659,26 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
             out.record_stream(main)
         return out
 
+    # the block's trailing reductions (split-K combines, LayerNorm / bias column sums) are queued and flushed as two
+    # launches at the end of the block (not when the weight gradients run on the side stream)
+    rq = ReduceQueue() if side is None else None
     # ---- MLP
     du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
-                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None, aux_kind=_aux_kind(act_dtype, act))  # (dy c_proj)*act'(u), colsum
-    dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)))) if need[11] else None
+                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None, aux_kind=_aux_kind(act_dtype, act),
+                       defer=rq)  # (dy c_proj)*act'(u), colsum
+    dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)), defer=rq)) if need[11] else None
     dy2 = p_dgrad(du, wfc_c, act_dtype)
-    dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)))) if need[9] else None
+    dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)), defer=rq)) if need[9] else None
     two = bf and not chain   # fp32 dx + its bf16 copy
     r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=res_in, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
                  outs=(_slot_out(s_ln2w, (D,)) if need[7] else None, _slot_out(s_ln2b, (D,)) if need[8] else None,
-                       _slot_out(s_bpr, (D,)) if need[12] else None))
+                       _slot_out(s_bpr, (D,)) if need[12] else None), defer=rq)
     dx1, dln2w, dln2b = r[0], r[1], r[2]
     dx1_16 = r[3] if two else dx1
     dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
     # ---- attention
     do = p_dgrad(dx1_16, wo_c, act_dtype)
-    dwo = on_side(lambda: p_wgrad(dx1_16, o, out=_slot_out(so, (D, D)))) if need[5] else None
+    dwo = on_side(lambda: p_wgrad(dx1_16, o, out=_slot_out(so, (D, D)), defer=rq)) if need[5] else None
     dqkv = _empty((M, 3 * D), act_dtype, x2)
     s3 = (T * 3 * D, 3 * D)
     ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
@@ -632,11 +686,13 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     part = _empty((B, 3 * D), torch.float32, x2) if (bf and need[4]) else None  # in_proj bias gradient per sample
     p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
     dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
-    dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)))) if need[3] else None
+    dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)), defer=rq)) if need[3] else None
     dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv, out=_slot_out(s_bqkv, (3 * D,)))) if need[4] else None
     r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
                  outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
-                       _slot_out(s_bo, (D,)) if need[6] else None))
+                       _slot_out(s_bo, (D,)) if need[6] else None), defer=rq)
+    if rq is not None:
+        rq.flush()
     dln1w, dln1b = r[1], r[2]
     dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
     if side is not None:

@@ -627,3 +627,37 @@ def test_res_stack_bf16_chain_depth12_width768():
           f"dx: chain {e_dx_chain:.3e}, bf16 {e_dx_bf:.3e}")
     assert worst_chain <= 3e-2 and e_dx_chain <= 3e-2, (worst_chain, e_dx_chain)
     assert worst_bf <= 2.5e-2 and e_dx_bf <= 1.5e-2, (worst_bf, e_dx_bf)
+
+
+def test_deferred_reductions_are_bit_identical():
+    """segclip_reduce_multi (one launch for a block's split-K combines / row reductions) against the producers' own
+    trailing reductions: same partials, same summation order -> bit-equal results."""
+    M, N, K = 6272, 512, 256
+    dy, x = rnd(M, N, dtype=BF, seed=61), rnd(M, K, dtype=BF, seed=62)
+    dy2, x2 = rnd(M, 256, dtype=BF, seed=63), rnd(M, 768, dtype=BF, seed=64)
+    ref1, ref2 = ops.p_wgrad(dy, x), ops.p_wgrad(dy2, x2)
+    q = ops.ReduceQueue()
+    out1, out2 = ops.p_wgrad(dy, x, defer=q), ops.p_wgrad(dy2, x2, defer=q)
+    assert len(q.slabs) == 2, "both weight gradients are expected to run split-K here"
+    # LayerNorm backward partials + a fused column sum in the same queue
+    rows, cols = 5000, 768
+    xs = rnd(rows, cols, seed=65)
+    w, b = 1 + 0.1 * rnd(cols, seed=66), 0.1 * rnd(cols, seed=67)
+    _, mean, rstd = ops.p_ln_fwd(xs, w, b, 1e-5, BF)
+    g, dres = rnd(rows, cols, dtype=BF, seed=68), rnd(rows, cols, dtype=BF, seed=69)
+    r0 = ops.p_ln_bwd(g, xs, w, mean, rstd, dres=dres, dx_dtype=BF, want_dres_colsum=True)
+    r1 = ops.p_ln_bwd(g, xs, w, mean, rstd, dres=dres, dx_dtype=BF, want_dres_colsum=True, defer=q)
+    r2 = ops.p_ln_bwd(g, xs, w, mean, rstd, dres=None, dx_dtype=F32, defer=q)
+    r3 = ops.p_ln_bwd(g, xs, w, mean, rstd, dres=None, dx_dtype=F32)
+    gy, wk, u = rnd(512, 256, dtype=BF, seed=70), rnd(256, 512, dtype=BF, seed=71, scale=256 ** -0.5), rnd(512, 512, dtype=BF, seed=72)
+    du0, cs0 = ops.p_dgrad(gy, wk, BF, aux=u, act=ops.ACT_QUICK_GELU, want_colsum=True)
+    du1, cs1 = ops.p_dgrad(gy, wk, BF, aux=u, act=ops.ACT_QUICK_GELU, want_colsum=True, defer=q)
+    assert len(q.rows) == 3
+    q.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(out1, ref1) and torch.equal(out2, ref2)
+    for a_, b_ in zip(r0, r1):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(r3, r2):
+        assert torch.equal(a_, b_)
+    assert torch.equal(du0, du1) and torch.equal(cs0, cs1)
