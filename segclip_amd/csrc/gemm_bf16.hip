@@ -459,6 +459,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.slab = (float*)d->ws;
   g.vec_epi = 0;
   g.touch = 0;
+  g.abl = 0;
   g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
   const bool fast = aligned16(d);

@@ -15,6 +15,7 @@ struct Args {
   int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
   float* colsum_part;  // optional [M/64][N] fp32 partial column sums of the stored output (LDS epilogue only)
   int vec_epi;  // host-checked: every C / aux / residual / bias access of a full tile may be a 16-byte vector
+  int abl;      // 8-phase kernel, timing experiments (SEGCLIP_P8_EPI_ABL): 1 = no epilogue (results garbage)
   int touch;    // 8-phase kernel: pre-touch the epilogue's side tile (SEGCLIP_P8_TOUCH, default on)
   int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u)
 };
@@ -183,13 +184,22 @@ template <> __device__ __forceinline__ void epi_side_get<float>(const f32x4& w, 
 
 __device__ __forceinline__ void epi_park(const Args& g, const f32x16 (&acc)[2][2], float* t, int lane) {
   const int li = lane & 31, lk = lane >> 5;
+  float* tl = t + (4 * lk) * EPI_PITCH + li;     // lane-constant part of the address: the rest are immediates
+  if (g.alpha == 1.0f) {                         // (uniform) the usual case: 64 multiplies less per sub-tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tl[(i * 32 + (r & 3) + 8 * (r >> 2)) * EPI_PITCH + j * 32] = acc[i][j][r];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        t[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_PITCH + j * 32 + li] = g.alpha * acc[i][j][r];
+      for (int r = 0; r < 16; ++r) tl[(i * 32 + (r & 3) + 8 * (r >> 2)) * EPI_PITCH + j * 32] = g.alpha * acc[i][j][r];
 }
 
 // one row segment: v[W] (LDS values) -> stored output; returns nothing, accumulates csum

@@ -28,6 +28,8 @@
 // after the barrier that follows them).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_bf16_common.h"
 
 namespace {
@@ -81,19 +83,36 @@ __device__ __forceinline__ uint32_t off_ks(int h, int idx, int lane, int64_t ld,
   return (uint32_t)((krow * ld + (r - row0)) * 2);
 }
 
-// MFMA 32x32x16 operand fragment: lane l -> row rbase + (l&31), k = kc*16 + 8*(l>>5) .. +7
-__device__ __forceinline__ bf16x8_t frag_direct(const char* unit, int rbase, int kc, int lane) {
+// ---- operand fragments.  The K loop reads 24 fragments per K-tile and wave; with the address arithmetic done per read
+// (row * pitch + swizzle) it spent ~94 VALU instructions per K-tile on addresses - in the R segments, which must stay
+// shorter than the partner group's 8 MFMAs.  Every fragment address is   lane base (VGPR, computed ONCE per kernel)
+// + compile-time constant (ring buffer, half-tile unit, 32-row block, k chunk), i.e. `ds_read ... offset:imm`:
+//   k-contiguous image [128 rows][128 B], 16-B chunk c stored at c ^ ((row>>1)&7): the chunk index c = 2 kc + (l>>5) enters
+//     through the XOR, so there is one base per kc (4 VGPRs per operand and ring buffer; the 16-bit DS offset cannot
+//     reach the second 64-KiB buffer from the first one's base);
+//   k-strided image [64 k][256 B], chunk (row>>3) stored at ^ ((k&3)<<2): kc is a pure row offset (kc * 16 * 256), the
+//     32-row block index flips a swizzled bit: one base per 32-row block.
+typedef __attribute__((address_space(3))) const char lds_cchar;
+typedef __attribute__((address_space(3))) const bf16x8_t lds_bf16x8;
+
+// lane l -> row rbase + (l&31), k = kc*16 + 8*(l>>5) .. +7;  rbase must be a multiple of 16 (it does not enter the swizzle)
+__device__ __forceinline__ uint32_t fragbase_direct(int rbase, int kc, int lane) {
   const int r = rbase + (lane & 31);
   const int c = kc * 2 + (lane >> 5);
-  return *reinterpret_cast<const bf16x8_t*>(unit + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+  return (uint32_t)(r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
 }
-__device__ __forceinline__ bf16x8_t frag_ks(const char* unit, int rbase, int kc, int lane) {
+__device__ __forceinline__ uint32_t fragbase_ks(int rbase, int lane) {   // kc = 0; + kc * 4096 for the others
   const int g4 = lane >> 4, q = lane & 15;
-  const int krow = kc * 16 + 8 * (g4 >> 1) + (q >> 2);
+  const int krow = 8 * (g4 >> 1) + (q >> 2);
   const int col = rbase + 16 * (g4 & 1) + 4 * (q & 3);
-  const char* p = unit + krow * 256 + ((((col >> 3) ^ ((krow & 3) << 2))) << 4) + ((col & 7) << 1);
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+  return (uint32_t)(krow * 256 + ((((col >> 3) ^ ((krow & 3) << 2))) << 4) + ((col & 7) << 1));
+}
+template <int OFF> __device__ __forceinline__ bf16x8_t frag_direct_at(lds_cchar* base) {
+  return *reinterpret_cast<lds_bf16x8*>(base + OFF);
+}
+template <int OFF> __device__ __forceinline__ bf16x8_t frag_ks_at(lds_cchar* base) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + OFF));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + OFF + 4 * 256));
   s16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -242,18 +261,56 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
       fa[0][kc] = fa[1][kc] = fbx[kc] = fby[kc] = __builtin_bit_cast(bf16x8_t, u32x4{(unsigned)lane, 1u, 2u, 3u});
     }
   }
-  auto read_a = [&](const char* unit) {
+  // lane bases of the fragment reads (see the fragment helpers): [ring buffer][kc] for a k-contiguous operand,
+  // [ring buffer][32-row block] for a k-strided one; made opaque so that the compiler keeps them in registers instead
+  // of re-deriving them in the K loop
+  lds_cchar* const sm3 = (lds_cchar*)smem;
+  lds_cchar* abase[2][4];
+  lds_cchar* bbase[2][4];
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      uint32_t oa = A_KS ? fragbase_ks(wr * 64 + (x & 1) * 32, lane) : fragbase_direct(wr * 64, x, lane);
+      uint32_t ob = B_KS ? fragbase_ks(wc * 32, lane) : fragbase_direct(wc * 32, x, lane);
+      oa += bf * BUF; ob += bf * BUF;
+      if ((!A_KS || x < 2)) asm volatile("" : "+v"(oa));
+      if ((!B_KS || x < 1)) asm volatile("" : "+v"(ob));
+      abase[bf][x] = sm3 + oa;
+      bbase[bf][x] = sm3 + ob;
+    }
+  // U: byte offset of the half-tile unit inside its ring buffer
+  auto read_a = [&](auto bfc, auto uc) {
+    constexpr int BF_ = decltype(bfc)::value, U = decltype(uc)::value;
     if constexpr (ABL == 3) return;
 #pragma unroll
-    for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc)
-        fa[ri][kc] = A_KS ? frag_ks(unit, wr * 64 + ri * 32, kc, lane) : frag_direct(unit, wr * 64 + ri * 32, kc, lane);
+    for (int ri = 0; ri < 2; ++ri) {
+      if constexpr (A_KS) {
+        fa[ri][0] = frag_ks_at<U + 0 * 4096>(abase[BF_][ri]);
+        fa[ri][1] = frag_ks_at<U + 1 * 4096>(abase[BF_][ri]);
+        fa[ri][2] = frag_ks_at<U + 2 * 4096>(abase[BF_][ri]);
+        fa[ri][3] = frag_ks_at<U + 3 * 4096>(abase[BF_][ri]);
+      } else {
+        if (ri == 0) {
+          fa[0][0] = frag_direct_at<U>(abase[BF_][0]); fa[0][1] = frag_direct_at<U>(abase[BF_][1]);
+          fa[0][2] = frag_direct_at<U>(abase[BF_][2]); fa[0][3] = frag_direct_at<U>(abase[BF_][3]);
+        } else {
+          fa[1][0] = frag_direct_at<U + 4096>(abase[BF_][0]); fa[1][1] = frag_direct_at<U + 4096>(abase[BF_][1]);
+          fa[1][2] = frag_direct_at<U + 4096>(abase[BF_][2]); fa[1][3] = frag_direct_at<U + 4096>(abase[BF_][3]);
+        }
+      }
+    }
   };
-  auto read_b = [&](const char* unit, bf16x8_t (&fb)[4]) {
+  auto read_b = [&](auto bfc, auto uc, bf16x8_t (&fb)[4]) {
+    constexpr int BF_ = decltype(bfc)::value, U = decltype(uc)::value;
     if constexpr (ABL == 3) return;
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) fb[kc] = B_KS ? frag_ks(unit, wc * 32, kc, lane) : frag_direct(unit, wc * 32, kc, lane);
+    if constexpr (B_KS) {
+      fb[0] = frag_ks_at<U + 0 * 4096>(bbase[BF_][0]); fb[1] = frag_ks_at<U + 1 * 4096>(bbase[BF_][0]);
+      fb[2] = frag_ks_at<U + 2 * 4096>(bbase[BF_][0]); fb[3] = frag_ks_at<U + 3 * 4096>(bbase[BF_][0]);
+    } else {
+      fb[0] = frag_direct_at<U>(bbase[BF_][0]); fb[1] = frag_direct_at<U>(bbase[BF_][1]);
+      fb[2] = frag_direct_at<U>(bbase[BF_][2]); fb[3] = frag_direct_at<U>(bbase[BF_][3]);
+    }
   };
   auto quadrant = [&](f32x16 (&c)[2][2], int j, const bf16x8_t (&fb)[4]) {
     if constexpr (ABL == 1) {  // keep the fragments live without issuing matrix instructions
@@ -272,34 +329,38 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  read_b(smem + 2 * UNIT, fbx);          // B0 of K-tile 0 (in the loop this read sits in R4 of the previous tile)
+  using std::integral_constant;
+  typedef integral_constant<int, 0> I0;
+  typedef integral_constant<int, 1> I1;
+  read_b(I0{}, integral_constant<int, 2 * UNIT>{}, fbx);   // B0 of K-tile 0 (in the loop this read sits in R4 of the previous tile)
   if (ABL != 4 && wr == 1) P8_BAR();     // group 1 runs one barrier interval behind group 0
 
   // one K-tile: fbp holds B0(t) on entry and fbq is free; on exit fbq holds B0(t+1)
-  auto ktile = [&](int t, bf16x8_t (&fbp)[4], bf16x8_t (&fbq)[4]) {
-    const char* buf = smem + (t & 1) * BUF;
-    const char* nbuf = smem + ((t + 1) & 1) * BUF;
+  // (bc = t & 1 as a type: the ring-buffer offset of every fragment read is a compile-time constant)
+  auto ktile = [&](auto bc, int t, bf16x8_t (&fbp)[4], bf16x8_t (&fbq)[4]) {
+    typedef decltype(bc) CB;
+    typedef integral_constant<int, 1 - CB::value> NB;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
     // ---- phase 1: quadrant (A0, B0)
-    read_a(buf);
+    read_a(CB{}, integral_constant<int, 0>{});
     if (n1) { stage(1, t + 1); wait_vm<10>(); } else { wait_vm<2>(); }          // retires B1(t), read in R2
     P8_BAR();
     quadrant(acc[0], 0, fbp);
     P8_BAR();
     // ---- phase 2: quadrant (A0, B1)
-    read_b(buf + 3 * UNIT, fbq);
+    read_b(CB{}, integral_constant<int, 3 * UNIT>{}, fbq);
     if (n2) { stage(2, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<8>(); } else { wait_vm<0>(); }   // retires A1(t)
     P8_BAR();
     quadrant(acc[0], 1, fbq);
     P8_BAR();
     // ---- phase 3: quadrant (A1, B1)
-    read_a(buf + UNIT);
+    read_a(CB{}, integral_constant<int, UNIT>{});
     if (n2) { stage(0, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<6>(); }   // retires B0(t+1), read in R4
     P8_BAR();
     quadrant(acc[1], 1, fbq);
     P8_BAR();
     // ---- phase 4: quadrant (A1, B0); B1's registers are free: B0(t+1) goes there
-    if (n1) read_b(nbuf + 2 * UNIT, fbq);
+    if (n1) read_b(NB{}, integral_constant<int, 2 * UNIT>{}, fbq);
     if (n2) { stage(3, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<4>(); }   // retires A0(t+1), read in R1
     P8_BAR();
     quadrant(acc[1], 0, fbp);
@@ -307,13 +368,26 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   };
   int t = 0;
   for (; t + 1 < nk; t += 2) {
-    ktile(t, fbx, fby);
-    ktile(t + 1, fby, fbx);
+    ktile(I0{}, t, fbx, fby);
+    ktile(I1{}, t + 1, fby, fbx);
   }
-  if (t < nk) ktile(t, fbx, fby);
+  if (t < nk) ktile(I0{}, t, fbx, fby);
   if (ABL != 4 && wr == 0) P8_BAR();  // group 0 catches up: both groups have executed the same number of barriers
 
   const int64_t nw = n0 + wc * 32;  // this wave's first column (second strip at +128)
+  if (g.abl == 1) {   // experiment: no epilogue at all (one conditional store keeps the accumulators alive)
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc += acc[i][ri][j][r];
+    if (sacc == 1.2345678f) reinterpret_cast<float*>(g.C)[lane] = sacc;
+    return;
+  }
   if (g.splits > 1) {
     const int li = lane & 31, lk = lane >> 5;
     float* slab = g.slab + ((int64_t)ksplit * gridDim.z + z) * g.M * g.N;
@@ -429,6 +503,8 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
   static const int touch = [] { const char* e = getenv("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
   static const int stagger = [] { const char* e = getenv("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 5000; }();   // unit cap in cycles; 0 = off
+  static const int epi_abl = [] { const char* e = getenv("SEGCLIP_P8_EPI_ABL"); return e ? atoi(e) : 0; }();
+  g.abl = epi_abl;
   g.touch = (touch ? 1 : 0) | (stagger > 0 ? 0 : 2) | (stagger << 2);   // bit 0: side-tile touch experiment, bit 1: no first-round stagger
   g.nbx = (int)cdiv(d->N, BT);
   g.nby = (int)cdiv(d->M, BT);
