@@ -56,6 +56,7 @@ def parse():
                     help="N>1 gradient exchange: segclip_amd.dist.GradSync (default) or torch DDP (comparison only)")
     ap.add_argument("--attn-fp8", default="auto", choices=["auto", "on", "off"],
                     help="e4m3 MFMA for QK^T / PV in the self-attention forward (auto: on for --spec vitl14_336 = configs[4])")
+    ap.add_argument("--text-after-blocks", type=int, default=-1, help="config.text_after_blocks override (launch order of the towers)")
     ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format (auto = fp32, what the reference DDP exchanges; bf16 is an opt-in)")
     return ap.parse_args()
 
@@ -245,7 +246,7 @@ def roofline_block(a, step, pairs_per_gpu, world):
     n, fl, nb = work["gemm_bf16"]
     classes = {"gemm_bf16": g, "attention_fwd": mfma("attn_fwd", "attn_fwd"), "attention_bwd": mfma("attn_bwd", "attn_bwd"),
                "layernorm_bwd": hbm("ln_bwd", "ln_bwd"), "layernorm_fwd": hbm("ln_fwd", "ln_fwd")}
-    for extra in ("splitk_reduce", "row_reductions", "gemm_f32", "other"):
+    for extra in ("splitk_reduce", "row_reductions", "gemm_f32", "other"):   # ("startup_probe" is not step work)
         if extra in cl:
             classes[extra] = {"time_per_step_ms": cl[extra]["time_per_step_ms"], "launches_per_step": cl[extra]["launches_per_step"]}
     tr = m["traffic"]
@@ -258,7 +259,7 @@ def roofline_block(a, step, pairs_per_gpu, world):
             "source": f"kernel durations of a rocprofv3 --kernel-trace --stats child run of this workload on one GPU ({ksteps + kwarm} model "
                       "passes, text tower concurrent on its second stream as in the timed region); flops / bytes counted by the op layer",
             "two_stream_note": "class times are sums of kernel durations on two concurrent streams: they may add up to more than ms_per_step",
-            "all_kernels_ms_per_step": round(sum(v["time_per_step_ms"] for v in cl.values()), 3),
+            "all_kernels_ms_per_step": round(sum(v["time_per_step_ms"] for k, v in cl.items() if k != "startup_probe"), 3),
             "classes": classes, "step_frac": step_frac, "notes": m["notes"]}
 
 
@@ -312,6 +313,8 @@ def main():
     segclip_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     attn_fp8 = a.dtype == "bf16" and (a.attn_fp8 == "on" or (a.attn_fp8 == "auto" and a.spec == "vitl14_336"))
     segclip_amd.config.attn_fp8 = attn_fp8
+    if a.text_after_blocks >= 0:
+        segclip_amd.config.text_after_blocks = a.text_after_blocks
     torch.manual_seed(1234 + rank)
     model, targs = synth.build_model(spec, flags, rank=rank, world_size=world, device=dev)
     # the reference driver freezes these two (main_task_align.py:436-441)
