@@ -20,10 +20,14 @@ out = sys.argv[1]
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        import re
+        m = re.search(r"(gemm_bf16\w*|splitk\w*|reduce_multi\w*)", r["Kernel_Name"])
+        if not m: continue
+        k = m.group(1)
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+        if r["Counter_Name"] in ("SQ_WAVE_CYCLES", "TCC_HIT_sum", "FETCH_SIZE"):
+            tot[k]["_ns_" + r["Counter_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); cnt[k]["_ns_" + r["Counter_Name"]] += 1
 for k in tot:
-    if "gemm" not in k and "splitk" not in k: continue
     print("==", k)
     for c in sorted(tot[k]):
         print("  %-34s %16.0f  (per launch %14.0f, %d launches)" % (c, tot[k][c], tot[k][c] / cnt[k][c], cnt[k][c]))
