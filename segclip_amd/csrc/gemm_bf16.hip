@@ -460,6 +460,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.vec_epi = 0;
   g.touch = 0;
   g.abl = 0;
+  g.colgroups = 1;
   g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
   const bool fast = aligned16(d);

@@ -15,6 +15,7 @@ struct Args {
   int splits; int64_t kper; float* slab;  // split-K: raw fp32 partial tiles go to slab[s][z][M][N]
   float* colsum_part;  // optional [M/64][N] fp32 partial column sums of the stored output (LDS epilogue only)
   int vec_epi;  // host-checked: every C / aux / residual / bias access of a full tile may be a 16-byte vector
+  int colgroups; // 8-phase kernel: column groups of the tile order (see the kernel); 1 = plain row-major
   int abl;      // 8-phase kernel, timing experiments (SEGCLIP_P8_EPI_ABL): 1 = no epilogue (results garbage)
   int touch;    // 8-phase kernel: pre-touch the epilogue's side tile (SEGCLIP_P8_TOUCH, default on)
   int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u)

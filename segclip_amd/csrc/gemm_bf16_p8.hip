@@ -153,7 +153,25 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int unit_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int wg = unit_id % nt, ksplit = unit_id / nt;
-  const int64_t n0 = (int64_t)(wg % g.nbx) * BT, m0 = (int64_t)(wg / g.nbx) * BT;
+  // Tile order inside the sequence that is cut into the 8 XCD chunks.  Default: row-major over all nbx column tiles.
+  // Experiment (g.colgroups = G > 1): the sequence walks column group 0 (all rows, its nbx/G columns, row-major), then
+  // group 1, ...: an XCD's chunk lies in one group (or two), its weight working set is 1/G of W; every A slab is read by
+  // G XCDs instead of one.  Hypothesis: row-major makes every XCD sweep the whole weight matrix once per round of its 32
+  // workgroups while the A slabs stream through the same 4-MiB L2 (the weights cost more K-loop time than the
+  // activations, tools/debug/gemm_latency_probe.py).  Measured: no gain (see the dispatcher).
+  int tcol, trow;
+  {
+    const int G = g.colgroups;
+    if (G <= 1) {
+      tcol = wg % g.nbx; trow = wg / g.nbx;
+    } else {
+      const int cq = g.nbx / G, cr = g.nbx % G;      // the first cr groups have cq + 1 columns
+      int rem = wg, c0 = 0, gi = 0, w = cq + (cr > 0 ? 1 : 0);
+      while (gi + 1 < G && rem >= w * g.nby) { rem -= w * g.nby; c0 += w; ++gi; w = cq + (gi < cr ? 1 : 0); }
+      tcol = c0 + rem % w; trow = rem / w;
+    }
+  }
+  const int64_t n0 = (int64_t)tcol * BT, m0 = (int64_t)trow * BT;
   const int64_t z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.bsA1 + z2 * g.bsA2;
   const bf16_t* B = g.B + z1 * g.bsB1 + z2 * g.bsB2;
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
     const long long cap = (long long)(g.touch >> 2);          // first-round stagger unit cap in cycles (default 5000)
     const long long unit = t_tile / 8 < cap ? t_tile / 8 : cap;
     // tiles of one block row share their A rows through the XCD's L2: they get the SAME delay and stay in lockstep
-    const long long wait = ((wg / g.nbx) & 7) * unit;
+    const long long wait = (trow & 7) * unit;
     const long long t0 = clock64();
     while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
@@ -508,6 +526,12 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   g.touch = (touch ? 1 : 0) | (stagger > 0 ? 0 : 2) | (stagger << 2);   // bit 0: side-tile touch experiment, bit 1: no first-round stagger
   g.nbx = (int)cdiv(d->N, BT);
   g.nby = (int)cdiv(d->M, BT);
+  // column groups of the tile order (experiment, SEGCLIP_P8_COLGROUPS = 2..4; default 1 = row-major): measured at
+  // M = 50176 (tools/bench_epi.py): within +-3 % of row-major on every shape (N = 3072: -4 % with 3 groups; N = 768 with
+  // 3 groups loses the A sharing: +18 %) - the weight refetch model in the kernel comment is not what bounds the K loop
+  static const int cg_env = [] { const char* e = getenv("SEGCLIP_P8_COLGROUPS"); return e ? atoi(e) : 0; }();
+  g.colgroups = splits > 1 ? 1 : (cg_env > 0 ? cg_env : 1);
+  if (g.colgroups > g.nbx) g.colgroups = g.nbx;
   g.splits = splits;
   g.kper = kper;
   {
