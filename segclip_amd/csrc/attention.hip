@@ -209,6 +209,7 @@ struct BwdArgs {
   const int* klen;     // nullable: valid keys per sample (fused kernel only)
   float* colsum_part;  // nullable: [B][3][H*hd] token sums of dQ | dK | dV (the in_proj bias gradient, per sample)
   int abl;             // experiments (SEGCLIP_ATTN_ABL): 0 = the kernel; see attention_sp.inc
+  int nitems;          // single-pass kernel: B * H items, walked by a persistent grid
 };
 
 constexpr int TMAX = 256;
@@ -638,6 +639,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.klen = (const int*)d->klen;
     static const int abl_env = [] { const char* e = getenv("SEGCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();
     a.abl = abl_env;
+    a.nitems = (int)(d->B * d->H);
     if (d->Tq > TMAX || d->Tk > TMAX) {
       SEGCLIP_REQUIRE(d->klen == nullptr, "attn_bwd bf16: klen needs sequences of at most %d tokens", TMAX);
       // long sequences: two streaming launches (dK,dV | dQ), 8 owned tiles per workgroup
@@ -677,10 +679,28 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
         SEGCLIP_REQUIRE(e == hipSuccess && e2 == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         sp_attr_set = true;
       }
-      if (d->causal || d->klen)
-        hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<true>, dim3((unsigned)(d->B * d->H)), dim3(tiles * 64), lds_sp, stream, a);
+      // persistent grid: as many workgroups as the chip holds at once (LDS / registers: 1 per CU at T = 197, more for the
+      // short text sequences); SEGCLIP_ATTN_BWD_GRID overrides the number per CU (0 = one workgroup per item)
+      const bool masked = d->causal || d->klen;
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            ncu <= 0)
+          ncu = 256;
+      }
+      static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_GRID"); return e ? atoi(e) : -1; }();
+      int per_cu = 0;
+      hipError_t eo = masked ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_sp_bf16_kernel<true>, tiles * 64, lds_sp)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_sp_bf16_kernel<false>, tiles * 64, lds_sp);
+      if (eo != hipSuccess || per_cu < 1) per_cu = 1;
+      if (grid_env > 0) per_cu = grid_env;
+      int64_t grid = grid_env == 0 ? a.nitems : (int64_t)ncu * per_cu;
+      if (grid > a.nitems) grid = a.nitems;
+      if (masked)
+        hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<true>, dim3((unsigned)grid), dim3(tiles * 64), lds_sp, stream, a);
       else
-        hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<false>, dim3((unsigned)(d->B * d->H)), dim3(tiles * 64), lds_sp, stream, a);
+        hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<false>, dim3((unsigned)grid), dim3(tiles * 64), lds_sp, stream, a);
       SEGCLIP_CHECK_LAUNCH("attn_bwd_sp_bf16");
       return 0;
     }

@@ -66,10 +66,10 @@ __device__ __forceinline__ void dma16x2(const char* base_uniform, uint32_t off0,
 
 // Per-lane byte offset (relative to the tile's first element of the operand) of DMA piece `idx` (1 KiB) of half-tile h.
 // k-contiguous operand X(row,k) = X[row*ld + k]: image [128 rows][128 B], piece = 8 rows, 16-B chunk ^ ((row>>1)&7).
-__device__ __forceinline__ uint32_t off_direct(int h, int idx, int lane, int64_t ld, int64_t row0, int64_t nrows) {
+__device__ __forceinline__ uint32_t off_direct(int h, int idx, int lane, int64_t ld, int64_t row0, int64_t nrows, int rmask = 0) {
   const int u = idx * 8 + (lane >> 3);
   const int chunk = (lane & 7) ^ ((u >> 1) & 7);
-  int64_t r = row0 + h * 128 + u;
+  int64_t r = row0 + h * 128 + (u & ~rmask);   // rmask: experiment (fewer distinct cache lines per DMA instruction)
   r = r < nrows ? r : nrows - 1;
   return (uint32_t)(((r - row0) * ld + chunk * 8) * 2);
 }
@@ -183,17 +183,23 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   const int nk = (int)((kend - kbeg) / BK);
 
   // uniform tile bases (bytes) + per-lane 32-bit offsets: the DMA address is SGPR base + VGPR offset
-  const char* baseA = reinterpret_cast<const char*>(A_KS ? A + kbeg * g.lda + m0 : A + m0 * g.lda + kbeg);
-  const char* baseB = reinterpret_cast<const char*>(B_KS ? B + kbeg * g.ldb + n0 : B + n0 * g.ldb + kbeg);
+  // experiments (SEGCLIP_P8_EPI_ABL = 2..5, wrong results): operand rows taken from a small window that stays cache-resident
+  const int64_t m0a = g.abl == 2 || g.abl == 4 ? (m0 & 511) : g.abl == 3 ? (m0 & 4095) : g.abl == 5 ? (m0 & 32767) : m0;
+  const int64_t n0b = g.abl == 4 ? (n0 & 511) : n0;
+  const char* baseA = reinterpret_cast<const char*>(A_KS ? A + kbeg * g.lda + m0a : A + m0a * g.lda + kbeg);
+  const char* baseB = reinterpret_cast<const char*>(B_KS ? B + kbeg * g.ldb + n0b : B + n0b * g.ldb + kbeg);
   const int64_t stepA = A_KS ? (int64_t)BK * g.lda * 2 : BK * 2;   // bytes per K-tile
   const int64_t stepB = B_KS ? (int64_t)BK * g.ldb * 2 : BK * 2;
+  // experiments 6..11: 4 / 2 / 1 distinct rows (cache lines) per DMA instruction, A and B (6-8) or B only (9-11)
+  const int rm_ = g.abl >= 6 && g.abl <= 11 ? (2 << ((g.abl - 6) % 3)) - 1 : 0;
+  const int rmaskA = g.abl >= 9 ? 0 : rm_, rmaskB = rm_;
   uint32_t offA[2][2], offB[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      offA[h][i] = A_KS ? off_ks(h, wave * 2 + i, lane, g.lda, m0, g.M) : off_direct(h, wave * 2 + i, lane, g.lda, m0, g.M);
-      offB[h][i] = B_KS ? off_ks(h, wave * 2 + i, lane, g.ldb, n0, g.N) : off_direct(h, wave * 2 + i, lane, g.ldb, n0, g.N);
+      offA[h][i] = A_KS ? off_ks(h, wave * 2 + i, lane, g.lda, m0, g.M) : off_direct(h, wave * 2 + i, lane, g.lda, m0, g.M, rmaskA);
+      offB[h][i] = B_KS ? off_ks(h, wave * 2 + i, lane, g.ldb, n0, g.N) : off_direct(h, wave * 2 + i, lane, g.ldb, n0, g.N, rmaskB);
     }
   // half-tile `u` (0: A0, 1: A1, 2: B0, 3: B1) of K-tile t -> ring buffer t&1
   const uint32_t lds_ring = (uint32_t)(uintptr_t)((lds_void*)smem) + wave * 2048;
