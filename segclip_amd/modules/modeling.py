@@ -15,6 +15,19 @@ from .module_mae import MAEDecoder
 from .util_module import CrossEn, PreTrainedModel, dist_collect, get_attr, get_logger, show_log
 
 
+def _detached(obj):
+    """Copy of a nest of dicts / lists / tuples with every tensor detached.  The `last_*` attributes are for inspection
+    (tests, logging): holding graph-attached tensors on the module would keep the previous step's autograd graph - and
+    with it the AccumulateGrad nodes of the stream that step ran on - alive, which breaks hipGraph capture of the step."""
+    if isinstance(obj, torch.Tensor):
+        return obj.detach()
+    if isinstance(obj, dict):
+        return {k: _detached(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_detached(v) for v in obj)
+    return obj
+
+
 class SegCLIPPreTrainedModel(PreTrainedModel, nn.Module):
     def __init__(self, *inputs, **kwargs):
         super().__init__()
@@ -179,7 +192,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
             sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
             visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
                                                                               return_hidden=True)
-        self.last_mid_states = mid_states
+        self.last_mid_states = _detached(mid_states)
         sim_matrix_t2v, sim_matrix_v2t = self._loose_similarity(sequence_output, visual_output)
         offset = sequence_output.size(0) * int(getattr(self.task_config, "rank", 0))
         sim_loss1 = ops.CrossEntropyFn.apply(sim_matrix_t2v, offset)
@@ -200,7 +213,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
             seq_mae_mask = seq_mae_mask.view(-1, seq_mae_mask.size(-1))
             seq_mae_ids_restore = seq_mae_ids_restore.view(-1, seq_mae_ids_restore.size(-1))
             _mae_mask = (seq_mae_mask + attention_mask).gt(1)
-            self.last_text_mae = (seq_mae_mask, seq_mae_ids_restore, seq_hidden)
+            self.last_text_mae = _detached((seq_mae_mask, seq_mae_ids_restore, seq_hidden))
             seq_mae_loss = self.seq_mae_decoder.forward_seq(input_ids, seq_hidden, _mae_mask, seq_mae_ids_restore,
                                                             attention_mask)
             loss = loss + seq_mae_loss
@@ -213,7 +226,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
             vis_hidden = torch.cat([cls_, vis_hidden], dim=1)
             vis_mae_mask = vis_mae_mask.view(-1, vis_mae_mask.size(-1))
             vis_mae_ids_restore = vis_mae_ids_restore.view(-1, vis_mae_ids_restore.size(-1))
-            self.last_mae = (vis_mae_mask, vis_mae_ids_restore, mid_mae_states)
+            self.last_mae = _detached((vis_mae_mask, vis_mae_ids_restore, mid_mae_states))
             vis_mae_loss = self.vis_mae_decoder.forward_vis(image, vis_hidden, vis_mae_mask, vis_mae_ids_restore,
                                                             loss_allpatch=False)
             loss = loss + vis_mae_loss
