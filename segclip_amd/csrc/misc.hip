@@ -182,6 +182,36 @@ __global__ void im2col_kernel(const float* __restrict__ img, void* __restrict__ 
     stx(cols, od, i, img[((b * C + c) * H + gy * p + py) * W + gx * p + px]);
   }
 }
+// layout 0 with p % 8 == 0 and ld % 8 == 0: one thread per 8 consecutive columns = 8 consecutive pixels of one patch row
+// (two 16-byte loads, one 16- or 32-byte store; one 64-bit division per 8 elements instead of five per element:
+// 256 x 3 x 224 x 224 -> bf16 209 -> ~50 us)
+__global__ void im2col_vec8_kernel(const float* __restrict__ img, void* __restrict__ cols, int64_t B, int C, int H, int W,
+                                   int p, int od, int64_t ld) {
+  const int gw = W / p, gh = H / p, ld8 = (int)(ld / 8), pp = p * p;
+  const int kdim = C * pp;
+  const int64_t total = B * gh * gw * ld8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / ld8;
+    const int col = (int)(i - row * ld8) * 8;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b4 = a;
+    if (col < kdim) {
+      const int c = col / pp, rem = col - c * pp, py = rem / p, px = rem - py * p;
+      const int r32 = (int)(row % (gh * gw));
+      const int64_t b = row / (gh * gw);
+      const int gy = r32 / gw, gx = r32 - gy * gw;
+      const float* src = img + ((b * C + c) * H + gy * p + py) * W + gx * p + px;
+      a = *reinterpret_cast<const f32x4*>(src);
+      b4 = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    if (od == SEGCLIP_BF16) {
+      u32x4 o = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b4[0], b4[1]), pack2bf(b4[2], b4[3])};
+      reinterpret_cast<u32x4*>(cols)[i] = o;
+    } else {
+      reinterpret_cast<f32x4*>(cols)[2 * i] = a;
+      reinterpret_cast<f32x4*>(cols)[2 * i + 1] = b4;
+    }
+  }
+}
 __global__ void vis_assemble_kernel(const void* __restrict__ patches, const float* __restrict__ cls,
                                     const float* __restrict__ pos, float* __restrict__ x, int64_t B, int T, int D, int pd) {
   const int64_t total = B * (T + 1) * D;
@@ -564,8 +594,13 @@ extern "C" int segclip_im2col_ld(const float* image, void* cols, int64_t B, int6
   SEGCLIP_REQUIRE(ld >= C * p * p, "im2col: ld=%lld < C*p*p=%lld", (long long)ld, (long long)(C * p * p));
   const int64_t total = B * (H / p) * (W / p) * ld;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid1d(total)), dim3(TPB), 0, ST, image, cols, B, (int)C, (int)H, (int)W, (int)p,
-                     layout, od, ld);
+  if (layout == 0 && p % 8 == 0 && ld % 8 == 0 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(cols) & 15) == 0 && (od == SEGCLIP_BF16 || od == SEGCLIP_F32))
+    hipLaunchKernelGGL(im2col_vec8_kernel, dim3(grid1d(total / 8)), dim3(TPB), 0, ST, image, cols, B, (int)C, (int)H, (int)W,
+                       (int)p, od, ld);
+  else
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid1d(total)), dim3(TPB), 0, ST, image, cols, B, (int)C, (int)H, (int)W, (int)p,
+                       layout, od, ld);
   SEGCLIP_CHECK_LAUNCH("im2col");
   return 0;
 }

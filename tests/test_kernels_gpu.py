@@ -392,6 +392,23 @@ def test_patch_embed_and_patchify():
     assert torch.equal(t, rt)
 
 
+@pytest.mark.parametrize("p,res,ldpad", [(16, 64, 0), (16, 224, 0), (14, 56, 52), (8, 32, 8)])
+def test_im2col_bit_exact(p, res, ldpad):
+    """conv1's im2col (module_clip_vtransformer / module_seg_vit patch embedding): the 8-pixels-per-thread kernel
+    (p % 8 == 0) and the per-element kernel (p = 14, K padded to the GEMM alignment) against torch unfold."""
+    from segclip_amd import _lib as L
+    B, C = 3, 3
+    img = rnd(B, C, res, res, seed=86)
+    kdim = C * p * p
+    ld = kdim + ldpad
+    ref = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, kdim)   # col = c*p*p + py*p + px
+    for dt in (F32, BF):
+        cols = torch.full((ref.shape[0], ld), float("nan"), dtype=dt, device=DEV)
+        L.check(L.load().segclip_im2col_ld(L.ptr(img), L.ptr(cols), B, C, res, res, p, 0, L.dt(cols), ld, L.stream()), "im2col")
+        assert torch.equal(cols[:, :kdim], ref.to(dt))
+        assert float(cols[:, kdim:].abs().sum()) == 0.0
+
+
 def test_embedding_gather_scatter():
     B, Lq, D, V = 5, 16, 64, 300
     g = torch.Generator().manual_seed(5)
