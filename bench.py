@@ -315,6 +315,8 @@ def main():
     segclip_amd.config.attn_fp8 = attn_fp8
     if a.text_after_blocks >= 0:
         segclip_amd.config.text_after_blocks = a.text_after_blocks
+    if os.environ.get("SEGCLIP_OVERLAP_WGRAD", "0") == "1":   # experiment switch: weight gradients on a second stream
+        segclip_amd.config.overlap_wgrad = True
     torch.manual_seed(1234 + rank)
     model, targs = synth.build_model(spec, flags, rank=rank, world_size=world, device=dev)
     # the reference driver freezes these two (main_task_align.py:436-441)
@@ -338,6 +340,10 @@ def main():
         loss.backward()
         return loss
 
+    if os.environ.get("SEGCLIP_MAIN_HIGH", "0") == "1":   # experiment: the step on a high-priority stream (gap-filler streams stay normal)
+        hs = torch.cuda.Stream(priority=-1)
+        hs.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hs)
     for _ in range(a.warmup):
         loss = step()
     torch.cuda.synchronize()

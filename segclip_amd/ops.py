@@ -10,6 +10,7 @@ path (fp32 residual stream, fp32 parameters / parameter gradients in both modes)
 """
 import ctypes as C
 import math
+import os
 import weakref
 
 import torch
@@ -96,6 +97,23 @@ class ReduceQueue:
 
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# Row pitch of the MLP hidden tensors (h, act'(u), du: M x 4D bf16).  A pitch that is a multiple of 2 KiB (4D = 3072 bf16 =
+# 6144 B) makes the 256-row store burst of every GEMM tile camp on a few HBM channels: with 1 KiB more per row the c_fc
+# forward with its two outputs runs 385 -> 312 us, the c_proj data gradient 324 -> 290 us, and the GEMMs that read these
+# tensors as their A operand 2-5 % faster (M = 50176; tools/debug/gemm_ldc_probe2.py).  SEGCLIP_HIDDEN_PAD = extra
+# elements per row (0 = dense).
+_HIDDEN_PAD = int(os.environ.get("SEGCLIP_HIDDEN_PAD", "512"))
+
+
+def _empty_pitched(shape, dtype, like):
+    """(M, N) view of a buffer whose row pitch avoids multiples of 2 KiB (dense when the pitch is harmless or M is small)."""
+    M, N = shape
+    esz = torch.empty((), dtype=dtype).element_size()
+    if _HIDDEN_PAD <= 0 or M < 4096 or (N * esz) % 2048 != 0:
+        return _empty(shape, dtype, like)
+    return torch.empty((M, N + _HIDDEN_PAD), dtype=dtype, device=like.device)[:, :N]
 
 
 def _off(t, off):
@@ -189,17 +207,20 @@ def p_cast(t, dtype):
     return out
 
 
-def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_dtype=None, w_kn=False, aux_kind=0):
+def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_dtype=None, w_kn=False, aux_kind=0,
+             pitched=False):
     """y = act(x w^T + bias) + residual.  x (M,K) view; w (N,K) [or (K,N) when w_kn]; same dtype family.
     want_aux: also return what the backward needs of the pre-activation u: u itself (aux_kind 0) or act'(u) (aux_kind 1)."""
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
     out_dtype = out_dtype or x.dtype
-    y = _empty((M, N), out_dtype, x)
-    aux = _empty((M, N), out_dtype, x) if (want_aux and act != ACT_NONE) else None
+    alloc = _empty_pitched if pitched else _empty
+    y = alloc((M, N), out_dtype, x)
+    aux = alloc((M, N), out_dtype, x) if (want_aux and act != ACT_NONE) else None
     sb = (1, w.stride(0)) if w_kn else (w.stride(0), 1)
-    p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, N, bias=bias, residual=residual,
-           ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=N, act=act, aux_kind=aux_kind)
+    p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, _ld(y), bias=bias, residual=residual,
+           ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux) if aux is not None else N, act=act,
+           aux_kind=aux_kind)
     return y, aux
 
 
@@ -208,21 +229,22 @@ def fused_colsum_ok(M, N, K, dtype):
     return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0
 
 
-def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None, aux_kind=0, defer=None):
+def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None, aux_kind=0, defer=None,
+            pitched=False):
     """dx = dy w   [* act'(aux)]  ;  dy (M,N), w (N,K) [or (K,N) when w_kn] -> (M,K)
     want_colsum: also return the column sums of dx (= bias gradient of the Linear that produced the
     pre-activation), fused into the GEMM epilogue when the shape allows, else by the colsum kernel."""
     M, N = dy.shape
     K = w.shape[0] if w_kn else w.shape[1]
-    dx = _empty((M, K), out_dtype, dy)
+    dx = (_empty_pitched if pitched else _empty)((M, K), out_dtype, dy)
     sb = (w.stride(0), 1) if w_kn else (1, w.stride(0))
     if aux is not None and aux.dtype != out_dtype:
         raise TypeError("dgrad: aux dtype must equal output dtype")
     cs = None
     if want_colsum and fused_colsum_ok(M, K, N, out_dtype) and dy.dtype == torch.bfloat16:
         cs = colsum_out if colsum_out is not None else _empty((K,), torch.float32, dy)
-    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, K, aux=aux, ldaux=K, act=act, mul_dact=aux is not None, colsum=cs,
-           aux_kind=aux_kind, defer=defer)
+    p_gemm(dy, w, dx, M, K, N, (_ld(dy), 1), sb, _ld(dx), aux=aux, ldaux=_ld(aux) if aux is not None else K, act=act,
+           mul_dact=aux is not None, colsum=cs, aux_kind=aux_kind, defer=defer)
     if want_colsum:
         return dx, (cs if cs is not None else p_colsum(dx, out=colsum_out))
     return dx
@@ -374,6 +396,12 @@ def p_attn_bwd(d, stats, do, dq, dk, dv, dqs, dks, dvs, dos, dq_off=0, dk_off=0,
 def _wgrad_stream():
     from . import streams
     return streams.side_stream("wgrad")
+
+
+# config.overlap_wgrad experiments (read once): SEGCLIP_WGRAD_JOIN=stack joins the weight-gradient stream once per
+# ResStackFn backward instead of once per block (the tensors it reads are kept alive until then); the stream's priority
+# comes from SEGCLIP_WGRAD_PRIO (segclip_amd/streams.py)
+_WGRAD_JOIN_STACK = os.environ.get("SEGCLIP_WGRAD_JOIN", "block") == "stack"
 
 
 def interp_pos_table(table, h, w):
@@ -605,7 +633,8 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
     x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
     y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
     # bf16 mode: the c_fc epilogue stores act'(u) (its exponential is already there), the c_proj dgrad multiplies by it
-    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act))
+    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act),
+                    pitched=act_dtype == torch.bfloat16)
     xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
     saved = (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c)
     return xo, saved
@@ -620,7 +649,7 @@ def _aux_kind(act_dtype, act):
     return 1 if (act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU) else 0
 
 
-def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False):
+def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None):
     """Hand-scheduled backward of one block.  g: fp32 (M, D) gradient of the block output or None; g16: its bf16 copy or
     None.  need[i]: gradient wanted for forward input i (0 = x, 1..12 = the parameters in forward order).
     chain=False: fp32 residual gradient in and out (plus the bf16 copy the LayerNorm backward emits for free).
@@ -665,7 +694,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     # ---- MLP
     du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
                        colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None, aux_kind=_aux_kind(act_dtype, act),
-                       defer=rq)  # (dy c_proj)*act'(u), colsum
+                       defer=rq, pitched=bf)  # (dy c_proj)*act'(u), colsum
     dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)), defer=rq)) if need[11] else None
     dy2 = p_dgrad(du, wfc_c, act_dtype)
     dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)), defer=rq)) if need[9] else None
@@ -696,7 +725,10 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     dln1w, dln1b = r[1], r[2]
     dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
     if side is not None:
-        main.wait_stream(side)  # every buffer the side stream read may be recycled after this point
+        if keep is not None:   # joined by the caller: until then nothing the side stream reads may be recycled
+            keep.extend(t for t in (g16, h, du, y2, dx1_16, o, dqkv, y1, part) if t is not None)
+        else:
+            main.wait_stream(side)  # every buffer the side stream read may be recycled after this point
     dx32 = None if chain else r[0]
     dx16 = r[0] if chain else (r[3] if two else None)
     return dx32, dx16, (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwpr, dbpr)
@@ -788,6 +820,7 @@ class ResStackFn(Function):
         saved = ctx.saved_tensors
         need_all = ctx.needs_input_grad
         out = [None] * (nblk * 12)
+        keep = [] if (ctx.overlap_wgrad and _WGRAD_JOIN_STACK) else None
         for b in reversed(range(nblk)):
             P = ctx.params[b * 12:(b + 1) * 12]
             sl = ctx.slots[b * 12:(b + 1) * 12]
@@ -795,7 +828,7 @@ class ResStackFn(Function):
             gslots = (sl[2], sl[4], sl[8], sl[10])
             vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
             cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
-                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad)
+                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep)
             for i, (p, gr, slot) in enumerate(zip(P, grads, sl)):
                 if gr is None:
                     continue
@@ -806,6 +839,9 @@ class ResStackFn(Function):
                     owner._on_grad(p)
                 else:
                     out[b * 12 + i] = gr
+        if keep is not None:
+            torch.cuda.current_stream().wait_stream(_wgrad_stream())
+            keep.clear()
         if ctx.chain:
             dx = p_cast(cur16, torch.float32)
         else:

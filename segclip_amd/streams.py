@@ -7,6 +7,8 @@ current stream (and with the side streams handed out before) with a pair of spin
 collisions (every 4th..5th pool stream shares the main stream's queue, tools/debug/stream_probe.py); the runtime can
 still re-assign queues later, which is what the larger queue count is for.
 """
+import os
+
 import torch
 
 _CACHE = {}      # (device index, role) -> stream
@@ -58,7 +60,9 @@ def side_stream(role, main=None):
     if st is not None:
         return st
     others = [s for (d, r), s in _CACHE.items() if d == main.device.index]
-    cands = [torch.cuda.Stream(device=main.device) for _ in range(_NCAND)]
+    prio = os.environ.get("SEGCLIP_WGRAD_PRIO") if role == "wgrad" else None   # experiment: low-priority gap filler
+    cands = [torch.cuda.Stream(device=main.device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device=main.device)
+             for _ in range(_NCAND)]
     cands = [c for c in cands if c != main and all(c != o for o in others)]
     good = [c for c in cands if overlaps(main, c)]
     best = next((c for c in good if all(overlaps(o, c) for o in others)), None)
