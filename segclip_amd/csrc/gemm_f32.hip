@@ -78,17 +78,21 @@ __device__ __forceinline__ void tile_store(float* lds, int64_t sk, int tid, cons
   }
 }
 
-// TI x TI MFMA tiles per wave, 2 x 2 waves: workgroup tile 64 TI x 64 TI, K-step BKT.
-//   <2, 32>: 128 x 128 tiles;  <1, 64>: 64 x 64 tiles for problems with few tiles (the 256 x 256 x 512 logits products of
-//   the contrastive head ran on FOUR workgroups and took 93 us each, un-overlapped, between the towers and the backward).
-template <int TI, int BKT>
+// TI x TI MFMA tiles per wave, WM x (4 / WM) waves: workgroup tile 32 TI WM x 32 TI (4 / WM), K-step BKT.
+//   <2, 32, 2>: 128 x 128 tiles;  <1, 64, 2>: 64 x 64 tiles for problems with few tiles (the 256 x 256 x 512 logits products
+//   of the contrastive head ran on FOUR workgroups and took 93 us each, un-overlapped, between the towers and the backward);
+//   <1, 32, 1>: 32 x 128 tiles for M <= 32 (the assignment logits of the semantic-group block: 8 centers x 196 patches x
+//   256 samples - on 128-row tiles 15/16 of the MFMA work multiplied zero rows: 194 -> 111 us; K-step 64 instead of 32: 187 us,
+//   the 20 KB of LDS per workgroup, i.e. 7 resident workgroups per CU, are what hides the staging latency).
+template <int TI, int BKT, int WM>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
-  constexpr int BM = 64 * TI, BN = 64 * TI, PITCH = BM + 1, NCH = BM * BKT / 1024;
+  constexpr int WN = 4 / WM, BM = 32 * TI * WM, BN = 32 * TI * WN, PA = BM + 1, PB = BN + 1;
+  constexpr int NCA = BM * BKT / 1024, NCB = BN * BKT / 1024;
   extern __shared__ __attribute__((aligned(16))) float smem_f32[];
   float* As = smem_f32;
-  float* Bs = smem_f32 + BKT * PITCH;
+  float* Bs = smem_f32 + BKT * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int64_t z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
   const float* A = g.A + z1 * g.bsA1 + z2 * g.bsA2;
   const float* B = g.B + z1 * g.bsB1 + z2 * g.bsB2;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int li = lane & 31, lk = lane >> 5;
-  float ra[NCH][4], rb[NCH][4];
+  float ra[NCA][4], rb[NCB][4];
   tile_load<BM, BKT>(A, m0, g.M, 0, g.K, g.sam, g.sak, tid, ra);
   tile_load<BN, BKT>(B, n0, g.N, 0, g.K, g.sbn, g.sbk, tid, rb);
   for (int64_t k0 = 0; k0 < g.K; k0 += BKT) {
@@ -116,13 +120,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       tile_load<BM, BKT>(A, m0, g.M, k0 + BKT, g.K, g.sam, g.sak, tid, ra);
       tile_load<BN, BKT>(B, n0, g.N, k0 + BKT, g.K, g.sbn, g.sbk, tid, rb);
     }
+    // a short last K-step (K = 8 in the weight-gradient-like product of the assignment logits) multiplies no padding
+    const int kmax = g.K - k0 < BKT ? (int)((g.K - k0 + 1) & ~1) : BKT;
 #pragma unroll 4
-    for (int kk = 0; kk < BKT; kk += 2) {
+    for (int kk = 0; kk < kmax; kk += 2) {
       float a[TI], b[TI];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) a[i] = As[(kk + lk) * PITCH + wm * 32 * TI + i * 32 + li];
+      for (int i = 0; i < TI; ++i) a[i] = As[(kk + lk) * PA + wm * 32 * TI + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < TI; ++j) b[j] = Bs[(kk + lk) * PITCH + wn * 32 * TI + j * 32 + li];
+      for (int j = 0; j < TI; ++j) b[j] = Bs[(kk + lk) * PB + wn * 32 * TI + j * 32 + li];
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -173,17 +179,21 @@ int segclip_gemm_f32_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.bsA1 = d->bsA1; g.bsA2 = d->bsA2; g.bsB1 = d->bsB1; g.bsB2 = d->bsB2; g.bsC1 = d->bsC1; g.bsC2 = d->bsC2; g.bsR1 = d->bsR1; g.bsR2 = d->bsR2;
   g.act = d->act; g.mul_dact = d->mul_dact; g.aux_kind = d->aux_kind; g.alpha = d->alpha;
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * g.nb2;
-  // fewer than half a chip of 128 x 128 tiles: 64 x 64 tiles (4x the workgroups), K-step 64.  256 x 256 x 512: 94 -> 39 us
-  // (K-step 128: 47 us - the time is the LDS staging and the one-accumulator MFMA chain of a wave, not the round trips)
+  // M <= 32: 32 x 128 tiles.  Otherwise, with fewer than half a chip of 128 x 128 tiles: 64 x 64 tiles (4x the workgroups),
+  // K-step 64.  256 x 256 x 512: 94 -> 39 us (K-step 128: 47 us - the time is the LDS staging and the one-accumulator MFMA
+  // chain of a wave, not the round trips)
   static const int force_small = [] { const char* e = getenv("SEGCLIP_GEMM_F32_SMALL"); return e ? atoi(e) : -1; }();
-  const bool small = force_small >= 0 ? force_small != 0 : cdiv(d->N, 128) * cdiv(d->M, 128) * nb < 128;
-  const int64_t bt = small ? 64 : 128;
-  dim3 grid((unsigned)cdiv(d->N, bt), (unsigned)cdiv(d->M, bt), (unsigned)nb);
+  const bool skinny = force_small != 0 && d->M <= 32;
+  const bool small = !skinny && (force_small >= 0 ? force_small != 0 : cdiv(d->N, 128) * cdiv(d->M, 128) * nb < 128);
+  const int64_t bm = skinny ? 32 : (small ? 64 : 128), bn = skinny ? 128 : (small ? 64 : 128);
+  dim3 grid((unsigned)cdiv(d->N, bn), (unsigned)cdiv(d->M, bm), (unsigned)nb);
   SEGCLIP_REQUIRE(grid.y <= 65535 && nb <= 65535, "gemm_f32: grid too large (M=%lld batch=%lld)",
                   (long long)d->M, (long long)nb);
-  constexpr size_t lds_small = 2 * 64 * 65 * sizeof(float), lds_big = 2 * 32 * 129 * sizeof(float);
-  if (small) hipLaunchKernelGGL((gemm_f32_kernel<1, 64>), grid, dim3(NT), lds_small, stream, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<2, 32>), grid, dim3(NT), lds_big, stream, g);
+  constexpr size_t lds_small = 2 * 64 * 65 * sizeof(float), lds_big = 2 * 32 * 129 * sizeof(float),
+                   lds_skinny = 32 * (33 + 129) * sizeof(float);
+  if (skinny) hipLaunchKernelGGL((gemm_f32_kernel<1, 32, 1>), grid, dim3(NT), lds_skinny, stream, g);
+  else if (small) hipLaunchKernelGGL((gemm_f32_kernel<1, 64, 2>), grid, dim3(NT), lds_small, stream, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<2, 32, 2>), grid, dim3(NT), lds_big, stream, g);
   SEGCLIP_CHECK_LAUNCH("gemm_f32");
   return 0;
 }

@@ -213,6 +213,9 @@ def _attn_ref(q, k, v, H, causal):
 @pytest.mark.parametrize("B,T,H,hd,causal", [(2, 196, 12, 64, False), (3, 77, 8, 64, True), (2, 8, 2, 64, False),
                                              (2, 197, 8, 48, False), (2, 17, 8, 8, False), (1, 48, 12, 64, False),
                                              (2, 256, 2, 64, True),
+                                             # more (batch, head) items than the persistent backward grid has workgroups:
+                                             # every workgroup walks 2-3 items with the next item's loads prefetched
+                                             (48, 196, 12, 64, False), (160, 77, 8, 64, True),
                                              # > 256 tokens: the streaming backward (ViT-L/14 at 336^2: 576 patches)
                                              (2, 576, 16, 64, False), (1, 300, 2, 64, True), (1, 784, 3, 64, False)])
 def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
