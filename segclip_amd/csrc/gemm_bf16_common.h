@@ -19,6 +19,7 @@ struct Args {
   int abl;      // 8-phase kernel, timing experiments (SEGCLIP_P8_EPI_ABL): 1 = no epilogue (results garbage)
   int touch;    // 8-phase kernel: pre-touch the epilogue's side tile (SEGCLIP_P8_TOUCH, default on)
   int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u)
+  int xw_epi;   // 8-phase kernel, bf16 outputs: cross-wave row pass (whole 128-byte lines per store; SEGCLIP_EPI_XW)
 };
 
 
@@ -160,6 +161,26 @@ template <typename CT, int NSPLIT> __device__ __forceinline__ int64_t epi_col(in
   return NSPLIT > 0 ? nw + ((cl * W) >> 5) * NSPLIT + ((cl * W) & 31) : nw + cl * W;
 }
 
+// Where a lane of the row pass reads its W values of a row (tl + row * EPI_PITCH) and where they go (global column n).
+//   default: the wave's own patch, its own columns - with NSPLIT > 0 (8-phase kernel) a wave's 64 columns are two 32-column
+//     strips NSPLIT apart, so a bf16 row segment of a wave is two 64-byte pieces: every store instruction writes half lines
+//     and every 128-byte line of the output is written by two different waves at different times;
+//   cross-wave (bf16 output, NSPLIT > 0; xw = patch of wave 0, all 8 patches parked and a workgroup barrier passed): wave
+//     (wr, wc) takes the 64 CONTIGUOUS columns n0 + 64 wc .. + 63 of its 64 rows: strip 2 wc from the patch of wave
+//     (wr, (2 wc) & 3), strip 2 wc + 1 from its neighbour's - whole 128-byte lines per row and store instruction.
+struct EpiLane { const float* tl; int64_t n; int rl; };
+template <typename CT, int NSPLIT>
+__device__ __forceinline__ EpiLane epi_lane(const float* t, int64_t nw, int lane, const float* xw, int wr, int wc, int64_t n0) {
+  using G = EpiGeom<CT>;
+  const int cl = lane % G::LPR, rl = lane / G::LPR;
+  if (sizeof(CT) == 2 && NSPLIT > 0 && xw != nullptr) {
+    const int strip = 2 * wc + (cl >> 2);               // 32-column strip of the 256-wide tile (bf16: 4 lanes per strip)
+    const int sw = wr * 4 + (strip & 3), half = strip >> 2;
+    return EpiLane{xw + sw * (EPI_WAVE_BYTES / 4) + half * 32 + (cl & 3) * G::W, n0 + wc * 64 + cl * G::W, rl};
+  }
+  return EpiLane{t + cl * G::W, epi_col<CT, NSPLIT>(nw, cl), rl};
+}
+
 // Side registers of a sub-tile: NIT 16-byte words per lane, of the OUTPUT element type (the host routes a residual whose
 // dtype differs from the output's to the per-element epilogue): u32x4 = 8 bf16 (W == 8) or f32x4 (W == 4).
 template <typename CT> struct EpiSideT { typedef u32x4 type; };
@@ -167,11 +188,11 @@ template <> struct EpiSideT<float> { typedef f32x4 type; };
 
 template <typename CT, int MODE, int NSPLIT>
 __device__ __forceinline__ void epi_side_load(const Args& g, typename EpiSideT<CT>::type (&sr)[EpiGeom<CT>::NIT], int64_t mw,
-                                              int64_t nw, int lane, int64_t coff, int64_t roff) {
+                                              const EpiLane& L, int64_t coff, int64_t roff) {
   using G = EpiGeom<CT>;
   typedef typename EpiSideT<CT>::type ST;
-  const int cl = lane % G::LPR, rl = lane / G::LPR;
-  const int64_t n = epi_col<CT, NSPLIT>(nw, cl);
+  const int rl = L.rl;
+  const int64_t n = L.n;
 #pragma unroll
   for (int it = 0; it < G::NIT; ++it) {
     const int64_t m = mw + it * G::RPI + rl;
@@ -273,11 +294,12 @@ __device__ __forceinline__ void epi_load_bias(const Args& g, float (&bias)[EpiGe
 // row pass with side operands (act' multiplier or residual) held in sr[]: fully unrolled
 template <typename CT, int MODE, int NSPLIT>
 __device__ __forceinline__ void epi_rows_side(const Args& g, const typename EpiSideT<CT>::type (&sr)[EpiGeom<CT>::NIT],
-                                              const float* t, int64_t mw, int64_t nw, int lane, int64_t coff) {
+                                              const EpiLane& L, int64_t mw, int64_t coff) {
   using G = EpiGeom<CT>;
   constexpr int W = G::W;
-  const int cl = lane % G::LPR, rl = lane / G::LPR;
-  const int64_t n = epi_col<CT, NSPLIT>(nw, cl);
+  const int rl = L.rl;
+  const int64_t n = L.n;
+  const float* t = L.tl;
   float bias[W], csum[W];
   epi_load_bias<CT, MODE>(g, bias, n);
 #pragma unroll
@@ -289,7 +311,7 @@ __device__ __forceinline__ void epi_rows_side(const Args& g, const typename EpiS
     float v[W];
 #pragma unroll
     for (int c = 0; c < W; c += 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + c);
       v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
     }
     float sd[W];   // exactly W entries: a wider array makes VectorCombine widen the side-register loads (-> scratch)
@@ -313,11 +335,12 @@ __device__ __forceinline__ void epi_rows_side(const Args& g, const typename EpiS
 // rolled loop, 4 at a time (fully unrolling it, as the side-operand form above does, spilled registers and cost the
 // QuickGELU epilogue +25 %).
 template <typename CT, int MODE, int NSPLIT>
-__device__ __forceinline__ void epi_rows_plain(const Args& g, const float* t, int64_t mw, int64_t nw, int lane, int64_t coff) {
+__device__ __forceinline__ void epi_rows_plain(const Args& g, const EpiLane& L, int64_t mw, int64_t coff) {
   using G = EpiGeom<CT>;
   constexpr int W = G::W;
-  const int cl = lane % G::LPR, rl = lane / G::LPR;
-  const int64_t n = epi_col<CT, NSPLIT>(nw, cl);
+  const int rl = L.rl;
+  const int64_t n = L.n;
+  const float* t = L.tl;
   float bias[W], csum[W];
   epi_load_bias<CT, MODE>(g, bias, n);
 #pragma unroll
@@ -332,7 +355,7 @@ __device__ __forceinline__ void epi_rows_plain(const Args& g, const float* t, in
       float v[W];
 #pragma unroll
       for (int c = 0; c < W; c += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + cl * W + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(t + row * EPI_PITCH + c);
         v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
       }
       epi_finish_row<CT, MODE>(g, v, bias, csum, m, n, coff);
@@ -344,37 +367,51 @@ __device__ __forceinline__ void epi_rows_plain(const Args& g, const float* t, in
   epi_colsum<CT>(g, csum, mw, n, rl);
 }
 
-// one sub-tile (gemm_bf16_dma.hip)
+// barrier between parking and the row pass: wave-private patches need none (a wave's LDS operations execute in order);
+// the cross-wave row pass reads its neighbour's patch
+__device__ __forceinline__ void epi_sync(bool xw) {
+  if (xw) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+}
+
+// one sub-tile (gemm_bf16_dma.hip; the 8-phase kernel's sequential fp32 path)
 template <typename CT, int MODE, int NSPLIT = 0>
 __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
                                              int lane, int64_t coff, int64_t roff) {
+  const EpiLane L = epi_lane<CT, NSPLIT>(t, nw, lane, nullptr, 0, 0, 0);
   if (MODE != EPI_DACT && !g.residual) {
     epi_park(g, acc, t, lane);
     __builtin_amdgcn_wave_barrier();
-    epi_rows_plain<CT, MODE, NSPLIT>(g, t, mw, nw, lane, coff);
+    epi_rows_plain<CT, MODE, NSPLIT>(g, L, mw, coff);
     return;
   }
   typename EpiSideT<CT>::type sr[EpiGeom<CT>::NIT];
-  epi_side_load<CT, MODE, NSPLIT>(g, sr, mw, nw, lane, coff, roff);
+  epi_side_load<CT, MODE, NSPLIT>(g, sr, mw, L, coff, roff);
   epi_park(g, acc, t, lane);
   __builtin_amdgcn_wave_barrier();
-  epi_rows_side<CT, MODE, NSPLIT>(g, sr, t, mw, nw, lane, coff);
+  epi_rows_side<CT, MODE, NSPLIT>(g, sr, L, mw, coff);
 }
 
 // two sub-tiles of one wave (gemm_bf16_p8.hip: rows mw0.. and mw1..): the side loads of the second are issued as soon
-// as the first sub-tile's accumulators are parked, and land under the first row pass
+// as the first sub-tile's accumulators are parked, and land under the first row pass.  xw != nullptr (bf16 outputs; every
+// wave of the workgroup is here): cross-wave row pass, see epi_lane.
 template <typename CT, int MODE, int NSPLIT>
 __device__ __forceinline__ void epilogue_lds2(const Args& g, const f32x16 (&acc0)[2][2], const f32x16 (&acc1)[2][2],
                                               float* t, int64_t mw0, int64_t mw1, int64_t nw, int lane, int64_t coff,
-                                              int64_t roff) {
+                                              int64_t roff, const float* xw = nullptr, int wr = 0, int wc = 0, int64_t n0 = 0) {
+  // measured (tools/bench_epi.py, M = 50176): act' data gradient 315 -> 294 us (its side loads become whole lines too),
+  // c_fc forward with the saved derivative 334 -> 327; the plain bias-only epilogues do not gain (qkv forward 185 = 185,
+  // out_proj data gradient 87.7 -> 92: three more workgroup barriers per tile) and keep the wave-private row pass
+  if (MODE == EPI_PLAIN) xw = nullptr;
+  const bool x = sizeof(CT) == 2 && NSPLIT > 0 && xw != nullptr;
+  const EpiLane L = epi_lane<CT, NSPLIT>(t, nw, lane, xw, wr, wc, n0);
   if (MODE != EPI_DACT && !g.residual) {
     epi_park(g, acc0, t, lane);
-    __builtin_amdgcn_wave_barrier();
-    epi_rows_plain<CT, MODE, NSPLIT>(g, t, mw0, nw, lane, coff);
-    __builtin_amdgcn_wave_barrier();
+    epi_sync(x);
+    epi_rows_plain<CT, MODE, NSPLIT>(g, L, mw0, coff);
+    epi_sync(x);
     epi_park(g, acc1, t, lane);
-    __builtin_amdgcn_wave_barrier();
-    epi_rows_plain<CT, MODE, NSPLIT>(g, t, mw1, nw, lane, coff);
+    epi_sync(x);
+    epi_rows_plain<CT, MODE, NSPLIT>(g, L, mw1, coff);
     return;
   }
 #ifndef EPI_F32_OVERLAP
@@ -389,15 +426,15 @@ __device__ __forceinline__ void epilogue_lds2(const Args& g, const f32x16 (&acc0
     return;
   }
   typename EpiSideT<CT>::type s0[EpiGeom<CT>::NIT], s1[EpiGeom<CT>::NIT];
-  epi_side_load<CT, MODE, NSPLIT>(g, s0, mw0, nw, lane, coff, roff);
+  epi_side_load<CT, MODE, NSPLIT>(g, s0, mw0, L, coff, roff);
   epi_park(g, acc0, t, lane);
-  epi_side_load<CT, MODE, NSPLIT>(g, s1, mw1, nw, lane, coff, roff);
-  __builtin_amdgcn_wave_barrier();
-  epi_rows_side<CT, MODE, NSPLIT>(g, s0, t, mw0, nw, lane, coff);
-  __builtin_amdgcn_wave_barrier();
+  epi_side_load<CT, MODE, NSPLIT>(g, s1, mw1, L, coff, roff);
+  epi_sync(x);
+  epi_rows_side<CT, MODE, NSPLIT>(g, s0, L, mw0, coff);
+  epi_sync(x);
   epi_park(g, acc1, t, lane);
-  __builtin_amdgcn_wave_barrier();
-  epi_rows_side<CT, MODE, NSPLIT>(g, s1, t, mw1, nw, lane, coff);
+  epi_sync(x);
+  epi_rows_side<CT, MODE, NSPLIT>(g, s1, L, mw1, coff);
 }
 
 template <typename CT, int NSPLIT = 0>
@@ -410,10 +447,11 @@ __device__ __forceinline__ void epilogue_lds_mode(const Args& g, const f32x16 (&
 template <typename CT, int NSPLIT>
 __device__ __forceinline__ void epilogue_lds2_mode(const Args& g, const f32x16 (&acc0)[2][2], const f32x16 (&acc1)[2][2],
                                                    float* t, int64_t mw0, int64_t mw1, int64_t nw, int lane,
-                                                   int64_t coff, int64_t roff) {
-  if (g.mul_dact) epilogue_lds2<CT, EPI_DACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff);
-  else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds2<CT, EPI_ACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff);
-  else epilogue_lds2<CT, EPI_PLAIN, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff);
+                                                   int64_t coff, int64_t roff, const float* xw = nullptr, int wr = 0,
+                                                   int wc = 0, int64_t n0 = 0) {
+  if (g.mul_dact) epilogue_lds2<CT, EPI_DACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
+  else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds2<CT, EPI_ACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
+  else epilogue_lds2<CT, EPI_PLAIN, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
 }
 
 }  // namespace

@@ -441,7 +441,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
     if (g.c_dtype == SEGCLIP_BF16) { epilogue_lds_mode<bf16_t, 128>(g, acc[0], tp, mw0, nw, lane, coff, roff); __builtin_amdgcn_wave_barrier(); epilogue_lds_mode<bf16_t, 128>(g, acc[1], tp, mw1, nw, lane, coff, roff); }
     else { epilogue_lds_mode<float, 128>(g, acc[0], tp, mw0, nw, lane, coff, roff); __builtin_amdgcn_wave_barrier(); epilogue_lds_mode<float, 128>(g, acc[1], tp, mw1, nw, lane, coff, roff); }
 #else
-    if (g.c_dtype == SEGCLIP_BF16) epilogue_lds2_mode<bf16_t, 128>(g, acc[0], acc[1], tp, mw0, mw1, nw, lane, coff, roff);
+    if (g.c_dtype == SEGCLIP_BF16)
+      epilogue_lds2_mode<bf16_t, 128>(g, acc[0], acc[1], tp, mw0, mw1, nw, lane, coff, roff,
+                                      g.xw_epi ? reinterpret_cast<const float*>(smem) : nullptr, wr, wc, n0);
     else epilogue_lds2_mode<float, 128>(g, acc[0], acc[1], tp, mw0, mw1, nw, lane, coff, roff);
 #endif
 #ifndef P8_TEST_NORETURN
