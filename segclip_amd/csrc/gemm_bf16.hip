@@ -461,7 +461,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.touch = 0;
   g.abl = 0;
   g.colgroups = 1;
-  static const int xw_epi = [] { const char* e = getenv("SEGCLIP_EPI_XW"); return e ? atoi(e) : 1; }();
+  static const int xw_epi = [] { const char* e = getenv("SEGCLIP_EPI_XW"); return e ? atoi(e) : 2; }();
   g.xw_epi = xw_epi;
   g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);

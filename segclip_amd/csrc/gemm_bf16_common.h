@@ -399,9 +399,11 @@ __device__ __forceinline__ void epilogue_lds2(const Args& g, const f32x16 (&acc0
                                               float* t, int64_t mw0, int64_t mw1, int64_t nw, int lane, int64_t coff,
                                               int64_t roff, const float* xw = nullptr, int wr = 0, int wc = 0, int64_t n0 = 0) {
   // measured (tools/bench_epi.py, M = 50176): act' data gradient 315 -> 294 us (its side loads become whole lines too),
-  // c_fc forward with the saved derivative 334 -> 327; the plain bias-only epilogues do not gain (qkv forward 185 = 185,
-  // out_proj data gradient 87.7 -> 92: three more workgroup barriers per tile) and keep the wave-private row pass
-  if (MODE == EPI_PLAIN) xw = nullptr;
+  // c_fc forward with the saved derivative 334 -> 327; the plain bias-only epilogues do not gain in isolation (qkv forward
+  // 185 = 185, out_proj data gradient 87.7 -> 92: three more workgroup barriers per tile) but do in the step, where the
+  // second stream competes for the L2's write ports: 45.23 -> 44.98 ms.  SEGCLIP_EPI_XW = 0 off / 1 not for the plain
+  // epilogues / 2 (default) all bf16 outputs
+  if (MODE == EPI_PLAIN && g.xw_epi < 2) xw = nullptr;
   const bool x = sizeof(CT) == 2 && NSPLIT > 0 && xw != nullptr;
   const EpiLane L = epi_lane<CT, NSPLIT>(t, nw, lane, xw, wr, wc, n0);
   if (MODE != EPI_DACT && !g.residual) {
