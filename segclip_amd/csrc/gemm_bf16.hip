@@ -463,6 +463,8 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.colgroups = 1;
   static const int xw_epi = [] { const char* e = getenv("SEGCLIP_EPI_XW"); return e ? atoi(e) : 2; }();
   g.xw_epi = xw_epi;
+  static const int slab_staged = [] { const char* e = getenv("SEGCLIP_P8_SLAB_STAGED"); return e ? atoi(e) : 1; }();
+  g.slab_staged = slab_staged;
   g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
   const bool fast = aligned16(d);

@@ -19,6 +19,7 @@ struct Args {
   int abl;      // 8-phase kernel, timing experiments (SEGCLIP_P8_EPI_ABL): 1 = no epilogue (results garbage)
   int touch;    // 8-phase kernel: pre-touch the epilogue's side tile (SEGCLIP_P8_TOUCH, default on)
   int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u)
+  int slab_staged; // 8-phase kernel: split-K partial tiles through the staged epilogue (SEGCLIP_P8_SLAB_STAGED)
   int xw_epi;   // 8-phase kernel, bf16 outputs: cross-wave row pass (whole 128-byte lines per store; SEGCLIP_EPI_XW)
 };
 

@@ -415,6 +415,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   if (g.splits > 1) {
     const int li = lane & 31, lk = lane >> 5;
     float* slab = g.slab + ((int64_t)ksplit * gridDim.z + z) * g.M * g.N;
+    // full tiles: the raw fp32 partial tile goes through the staged epilogue (park, 16-byte row stores: 32 store
+    // instructions per wave instead of 128 one-dword stores); SEGCLIP_P8_SLAB_STAGED=0 keeps the per-element stores
+    if (g.slab_staged && m0 + BT <= g.M && n0 + BT <= g.N && g.N % 4 == 0) {
+      Args g2 = g;
+      g2.C = slab; g2.ldc = g.N; g2.c_dtype = SEGCLIP_F32; g2.bias = nullptr; g2.residual = nullptr; g2.aux = nullptr;
+      g2.act = SEGCLIP_ACT_NONE; g2.mul_dact = 0; g2.colsum_part = nullptr; g2.alpha = 1.0f;
+      __syncthreads();  // every wave is done with the operand ring
+      float* tps = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+      epilogue_lds2<float, EPI_PLAIN, 128>(g2, acc[0], acc[1], tps, m0 + wr * 64, m0 + 128 + wr * 64, nw, lane, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
