@@ -94,6 +94,7 @@ struct FwdArgs {
   int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
   float scale; int causal;
   const int* klen;  // nullable: valid keys per sample
+  int staged;       // bf16 forward: output rows through LDS (SEGCLIP_ATTN_FWD_STAGED)
 };
 
 constexpr int KCHUNK = 256;
@@ -180,6 +181,36 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt + 16, dt * 32, lane), pb1, o[dt], 0, 0, 0);
       }
     }
+  }
+  // Output.  The accumulators hold transposed tiles (lane = query row, registers = 4 consecutive columns): stored from
+  // registers every instruction touches 32 rows with 8 bytes each.  With SEGCLIP_ATTN_FWD_STAGED (a.staged) the tile goes
+  // through the wave's own 4 KB of the K tile instead (free once every wave has left the key loop): 8-byte LDS writes,
+  // 16-byte reads of whole 128-byte rows, 16-byte coalesced global stores.
+  if (a.staged) {
+    __syncthreads();
+    if (!wave_active) return;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    char* ot = Kt + wave * 32 * ROWB;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        u32x2 t;
+        t[0] = pack2bf(o[dt][rg * 4 + 0] * inv, o[dt][rg * 4 + 1] * inv);
+        t[1] = pack2bf(o[dt][rg * 4 + 2] * inv, o[dt][rg * 4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(ot + swz(li, dt * 32 + 8 * rg + 4 * lh)) = t;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    bf16_t* Ob = a.O + (int64_t)b * a.o_sb + (int64_t)h * a.hd;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 64 + lane, r = idx >> 3, c = idx & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ot + swz(r, c * 8));
+      if (q0 + r < a.Tq && c * 8 < a.hd) *reinterpret_cast<u32x4*>(Ob + (int64_t)(q0 + r) * a.o_st + c * 8) = v;
+    }
+    if (lh == 0 && qg < a.Tq) a.lse[((int64_t)b * a.H + h) * a.Tq + qg] = (l > 0.f) ? m * 0.6931471805599453f + __logf(l) : -INFINITY;
+    return;
   }
   if (!wave_active || qg >= a.Tq) return;
   const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -581,6 +612,9 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st;
     a.o_sb = d->o_sb; a.o_st = d->o_st; a.scale = d->scale; a.causal = d->causal;
     a.klen = (const int*)d->klen;
+    // LDS-staged output rows: 117 -> 112 us at T = 196 (B = 256, H = 12), 27.8 -> 29.3 us at T = 77: on for the long sequences
+    static const int fwd_staged = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_STAGED"); return e ? atoi(e) : -1; }();
+    a.staged = fwd_staged >= 0 ? fwd_staged : (d->Tq > 128 ? 1 : 0);
     SEGCLIP_REQUIRE(!(d->klen && (d->flags & SEGCLIP_ATTN_FP8)), "attn_fwd: klen is not supported by the fp8 kernel");
     const int tiles = (int)cdiv(d->Tq, 32);
     const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
