@@ -47,6 +47,10 @@ const char* segclip_last_error_string(void);
  *   mul_dact: v = v * act'(aux(m,n))   (aux is an INPUT: the saved pre-activation; bias/residual unused)
  *   aux_kind 1: aux holds act'(pre-activation) instead of the pre-activation - the forward epilogue stores the
  *               derivative (its exponential is already computed there) and mul_dact multiplies by aux as it is
+ *   aux_kind 2: as 1, but aux is ONE BYTE per element, q = rint((act'(v) + 0.125) * 204) (QuickGELU': [-0.10, 1.10],
+ *               absolute error <= 0.0025); ldaux in bytes; bf16 operands and output, full 256 x 256 tiles (M, N
+ *               multiples of 256), 16-byte aligned operands, ldaux % 8 == 0, no split-K - otherwise
+ *               SEGCLIP_ERR_UNSUPPORTED (callers fall back to aux_kind 1)
  * Replaces nn.Linear / MHA in-proj / out-proj / the einsum + Conv1d contractions:
  *   modules/module_seg_vit.py:166-172,189,266-269,304,309 ; modules/module_clip_ttransformer.py:24-30 ;
  *   modules/module_clip.py:91-94,131-134 ; modules/modeling.py:356-357 and their autograd backward
@@ -74,7 +78,7 @@ typedef struct segclip_gemm_desc {
   int32_t act;
   int32_t mul_dact;
   float alpha;
-  int32_t aux_kind; /* 0: aux = pre-activation; 1: aux = act'(pre-activation) */
+  int32_t aux_kind; /* 0: aux = pre-activation; 1: aux = act'(pre-activation); 2: the same as one byte per element */
   void* ws;         /* optional split-K scratch (bf16 path, plain epilogue only); NULL = no split-K */
   int64_t ws_bytes; /* size of ws; segclip_gemm_ws_bytes(d) is the amount that enables split-K */
   float* colsum;    /* optional [N] fp32: column sums of the stored C (bias gradient fused into the epilogue).

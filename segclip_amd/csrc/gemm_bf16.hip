@@ -489,6 +489,10 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     segclip_set_error("gemm: fused colsum unsupported for this shape");
     return SEGCLIP_ERR_UNSUPPORTED;
   }
+  if (!launched && d->aux_kind == 2 && d->aux) {
+    segclip_set_error("gemm: aux_kind 2 needs full 256 x 256 tiles, 16-byte aligned operands and no split-K");
+    return SEGCLIP_ERR_UNSUPPORTED;
+  }
   if (!launched) {
     if (!a_ks && !b_ks) segclip_gb_launch_ff(a_f32, fast, grid, stream, &g);
     else if (!a_ks && b_ks) segclip_gb_launch_fk(a_f32, fast, grid, stream, &g);

@@ -18,14 +18,22 @@ struct Args {
   int colgroups; // 8-phase kernel: column groups of the tile order (see the kernel); 1 = plain row-major
   int abl;      // 8-phase kernel, timing experiments (SEGCLIP_P8_EPI_ABL): 1 = no epilogue (results garbage)
   int touch;    // 8-phase kernel: pre-touch the epilogue's side tile (SEGCLIP_P8_TOUCH, default on)
-  int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u)
+  int aux_kind; // 0: aux = pre-activation u (stored by EPI_ACT, differentiated by EPI_DACT); 1: aux = act'(u);
+                // 2: aux = act'(u) as one byte per element (staged epilogue only, see EPI_ACT8)
   int slab_staged; // 8-phase kernel: split-K partial tiles through the staged epilogue (SEGCLIP_P8_SLAB_STAGED)
   int xw_epi;   // 8-phase kernel, bf16 outputs: cross-wave row pass (whole 128-byte lines per store; SEGCLIP_EPI_XW)
 };
 
 
 // ---- epilogue -------------------------------------------------------------------------------
-enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
+// EPI_ACT8 / EPI_DACT8 (bf16 outputs, QuickGELU, staged epilogue of full tiles only): the saved derivative act'(u), which lies
+// in [-0.10, 1.10], is kept as ONE BYTE per element, q = rint((act'(u) + 0.125) * 204): absolute error <= 0.0025, i.e. about
+// bf16's relative error at the typical magnitude - and half the bytes of the largest side tensor of a block (M x 4D written
+// by the c_fc forward, read by the c_proj data gradient: without ANY of that traffic the step is 1.4 ms shorter).
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2, EPI_ACT8 = 3, EPI_DACT8 = 4 };
+constexpr bool epi_is_act(int m) { return m == EPI_ACT || m == EPI_ACT8; }
+constexpr bool epi_is_dact(int m) { return m == EPI_DACT || m == EPI_DACT8; }
+constexpr float AUX8_SCALE = 204.0f, AUX8_OFF = 0.125f;
 
 // forward activation epilogue: v (pre-activation) -> act(v); *side = what is kept for the backward: u, or act'(u) when
 // aux_kind == 1 (QuickGELU only - segclip_gemm rejects aux_kind 1 with any other activation; keeping the erf-GELU
@@ -197,7 +205,11 @@ __device__ __forceinline__ void epi_side_load(const Args& g, typename EpiSideT<C
 #pragma unroll
   for (int it = 0; it < G::NIT; ++it) {
     const int64_t m = mw + it * G::RPI + rl;
-    if (MODE == EPI_DACT) sr[it] = *reinterpret_cast<const ST*>((const CT*)g.aux + coff + m * g.ldaux + n);
+    if constexpr (MODE == EPI_DACT8) {
+      const u32x2 q = *reinterpret_cast<const u32x2*>((const uint8_t*)g.aux + coff + m * g.ldaux + n);
+      sr[it] = ST{};
+      sr[it][0] = q[0]; sr[it][1] = q[1];
+    } else if (MODE == EPI_DACT) sr[it] = *reinterpret_cast<const ST*>((const CT*)g.aux + coff + m * g.ldaux + n);
     else sr[it] = *reinterpret_cast<const ST*>((const CT*)g.residual + roff + m * g.ldr + n);
   }
 }
@@ -230,15 +242,21 @@ template <typename CT, int MODE>
 __device__ __forceinline__ void epi_finish_row(const Args& g, float (&v)[EpiGeom<CT>::W], const float (&bias)[EpiGeom<CT>::W],
                                                float (&csum)[EpiGeom<CT>::W], int64_t m, int64_t n, int64_t coff) {
   constexpr int W = EpiGeom<CT>::W;
-  if (MODE != EPI_DACT) {
+  if (!epi_is_dact(MODE)) {
 #pragma unroll
     for (int c = 0; c < W; ++c) v[c] += bias[c];
   }
-  if (MODE == EPI_ACT) {
+  if (epi_is_act(MODE)) {
     float sd[W];
 #pragma unroll
-    for (int c = 0; c < W; ++c) v[c] = act_with_side(g.act, g.aux_kind, v[c], &sd[c]);
-    if (g.aux) {
+    for (int c = 0; c < W; ++c) v[c] = act_with_side(g.act, MODE == EPI_ACT8 ? 1 : g.aux_kind, v[c], &sd[c]);
+    if constexpr (MODE == EPI_ACT8) {
+      u32x2 q = {0u, 0u};
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        q[c >> 2] = __builtin_amdgcn_cvt_pk_u8_f32((sd[c] + AUX8_OFF) * AUX8_SCALE, c & 3, q[c >> 2]);
+      __builtin_nontemporal_store(q, reinterpret_cast<u32x2*>((uint8_t*)g.aux + coff + m * g.ldaux + n));
+    } else if (g.aux) {
       if (sizeof(CT) == 2) {
         u32x4 p;
 #pragma unroll
@@ -283,7 +301,7 @@ __device__ __forceinline__ void epi_load_bias(const Args& g, float (&bias)[EpiGe
   constexpr int W = EpiGeom<CT>::W;
 #pragma unroll
   for (int c = 0; c < W; ++c) bias[c] = 0.f;
-  if (MODE != EPI_DACT && g.bias) {
+  if (!epi_is_dact(MODE) && g.bias) {
 #pragma unroll
     for (int c = 0; c < W; c += 4) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n + c);
@@ -316,8 +334,18 @@ __device__ __forceinline__ void epi_rows_side(const Args& g, const typename EpiS
       v[c] = a[0]; v[c + 1] = a[1]; v[c + 2] = a[2]; v[c + 3] = a[3];
     }
     float sd[W];   // exactly W entries: a wider array makes VectorCombine widen the side-register loads (-> scratch)
-    epi_side_get<CT>(sr[it], sd);
-    if (MODE == EPI_DACT) {
+    if constexpr (MODE == EPI_DACT8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t w = sr[it][c >> 2];
+        const float qf = (float)((w >> (8 * (c & 3))) & 0xffu);   // v_cvt_f32_ubyteN
+        v[c] *= qf * (1.0f / AUX8_SCALE) - AUX8_OFF;
+      }
+    } else {
+      epi_side_get<CT>(sr[it], sd);
+    }
+    if constexpr (MODE == EPI_DACT8) {
+    } else if (MODE == EPI_DACT) {
 #pragma unroll
       for (int c = 0; c < W; ++c) v[c] *= dact_from_side(g.act, g.aux_kind, sd[c]);
     } else {
@@ -379,7 +407,7 @@ template <typename CT, int MODE, int NSPLIT = 0>
 __device__ __forceinline__ void epilogue_lds(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw, int64_t nw,
                                              int lane, int64_t coff, int64_t roff) {
   const EpiLane L = epi_lane<CT, NSPLIT>(t, nw, lane, nullptr, 0, 0, 0);
-  if (MODE != EPI_DACT && !g.residual) {
+  if (!epi_is_dact(MODE) && !g.residual) {
     epi_park(g, acc, t, lane);
     __builtin_amdgcn_wave_barrier();
     epi_rows_plain<CT, MODE, NSPLIT>(g, L, mw, coff);
@@ -407,7 +435,7 @@ __device__ __forceinline__ void epilogue_lds2(const Args& g, const f32x16 (&acc0
   if (MODE == EPI_PLAIN && g.xw_epi < 2) xw = nullptr;
   const bool x = sizeof(CT) == 2 && NSPLIT > 0 && xw != nullptr;
   const EpiLane L = epi_lane<CT, NSPLIT>(t, nw, lane, xw, wr, wc, n0);
-  if (MODE != EPI_DACT && !g.residual) {
+  if (!epi_is_dact(MODE) && !g.residual) {
     epi_park(g, acc0, t, lane);
     epi_sync(x);
     epi_rows_plain<CT, MODE, NSPLIT>(g, L, mw0, coff);
@@ -443,6 +471,13 @@ __device__ __forceinline__ void epilogue_lds2(const Args& g, const f32x16 (&acc0
 template <typename CT, int NSPLIT = 0>
 __device__ __forceinline__ void epilogue_lds_mode(const Args& g, const f32x16 (&acc)[2][2], float* t, int64_t mw,
                                                   int64_t nw, int lane, int64_t coff, int64_t roff) {
+  if constexpr (sizeof(CT) == 2) {
+    if (g.aux_kind == 2 && g.aux) {
+      if (g.mul_dact) epilogue_lds<CT, EPI_DACT8, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
+      else epilogue_lds<CT, EPI_ACT8, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
+      return;
+    }
+  }
   if (g.mul_dact) epilogue_lds<CT, EPI_DACT, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
   else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds<CT, EPI_ACT, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
   else epilogue_lds<CT, EPI_PLAIN, NSPLIT>(g, acc, t, mw, nw, lane, coff, roff);
@@ -452,6 +487,13 @@ __device__ __forceinline__ void epilogue_lds2_mode(const Args& g, const f32x16 (
                                                    float* t, int64_t mw0, int64_t mw1, int64_t nw, int lane,
                                                    int64_t coff, int64_t roff, const float* xw = nullptr, int wr = 0,
                                                    int wc = 0, int64_t n0 = 0) {
+  if constexpr (sizeof(CT) == 2) {
+    if (g.aux_kind == 2 && g.aux) {
+      if (g.mul_dact) epilogue_lds2<CT, EPI_DACT8, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
+      else epilogue_lds2<CT, EPI_ACT8, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
+      return;
+    }
+  }
   if (g.mul_dact) epilogue_lds2<CT, EPI_DACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
   else if (g.act != SEGCLIP_ACT_NONE) epilogue_lds2<CT, EPI_ACT, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);
   else epilogue_lds2<CT, EPI_PLAIN, NSPLIT>(g, acc0, acc1, t, mw0, mw1, nw, lane, coff, roff, xw, wr, wc, n0);

@@ -148,8 +148,8 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     d.bsR1, d.bsR2 = bsC if bsR is None else bsR
     d.a_dtype, d.b_dtype, d.c_dtype = L.dt(A), L.dt(B), L.dt(Cc)
     d.r_dtype = L.dt(residual) if residual is not None else L.F32
-    if aux is not None and aux.dtype != Cc.dtype:
-        raise TypeError("gemm: aux dtype must equal output dtype")
+    if aux is not None and aux.dtype != (torch.uint8 if aux_kind == 2 else Cc.dtype):
+        raise TypeError("gemm: aux dtype must equal output dtype (uint8 for aux_kind 2)")
     d.act, d.mul_dact, d.alpha, d.aux_kind = act, int(mul_dact), float(alpha), int(aux_kind)
     flags = 0
     if colsum is not None:
@@ -216,7 +216,7 @@ def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_d
     out_dtype = out_dtype or x.dtype
     alloc = _empty_pitched if pitched else _empty
     y = alloc((M, N), out_dtype, x)
-    aux = alloc((M, N), out_dtype, x) if (want_aux and act != ACT_NONE) else None
+    aux = alloc((M, N), torch.uint8 if aux_kind == 2 else out_dtype, x) if (want_aux and act != ACT_NONE) else None
     sb = (1, w.stride(0)) if w_kn else (w.stride(0), 1)
     p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, _ld(y), bias=bias, residual=residual,
            ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux) if aux is not None else N, act=act,
@@ -238,8 +238,8 @@ def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=Fa
     K = w.shape[0] if w_kn else w.shape[1]
     dx = (_empty_pitched if pitched else _empty)((M, K), out_dtype, dy)
     sb = (w.stride(0), 1) if w_kn else (1, w.stride(0))
-    if aux is not None and aux.dtype != out_dtype:
-        raise TypeError("dgrad: aux dtype must equal output dtype")
+    if aux is not None and aux.dtype != (torch.uint8 if aux_kind == 2 else out_dtype):
+        raise TypeError("dgrad: aux dtype must equal output dtype (uint8 for aux_kind 2)")
     cs = None
     if want_colsum and fused_colsum_ok(M, K, N, out_dtype) and dy.dtype == torch.bfloat16:
         cs = colsum_out if colsum_out is not None else _empty((K,), torch.float32, dy)
@@ -633,7 +633,7 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
     x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
     y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
     # bf16 mode: the c_fc epilogue stores act'(u) (its exponential is already there), the c_proj dgrad multiplies by it
-    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act),
+    h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act, y2.shape[0], wfc_c.shape[0]),
                     pitched=act_dtype == torch.bfloat16)
     xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
     saved = (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c)
@@ -643,10 +643,16 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
 N_SAVED = 19
 
 
-def _aux_kind(act_dtype, act):
-    """What the residual blocks keep of the MLP pre-activation: act'(u) in bf16 mode with QuickGELU (the towers), u itself
-    in the exact-f32 mode and for the erf-GELU of the MAE decoders."""
-    return 1 if (act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU) else 0
+_AUX_U8 = os.environ.get("SEGCLIP_AUX_U8", "1") != "0"
+
+
+def _aux_kind(act_dtype, act, M=0, N=0):
+    """What the residual blocks keep of the MLP pre-activation: act'(u) in bf16 mode with QuickGELU (the towers) - as one
+    byte per element (aux_kind 2: half the bytes of the block's largest side tensor) when the GEMM runs on full 256 x 256
+    tiles, else as bf16 -, u itself in the exact-f32 mode and for the erf-GELU of the MAE decoders."""
+    if act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU:
+        return 2 if (_AUX_U8 and M > 0 and M % 256 == 0 and N % 256 == 0) else 1
+    return 0
 
 
 def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None):
@@ -693,7 +699,8 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     rq = ReduceQueue() if side is None else None
     # ---- MLP
     du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
-                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None, aux_kind=_aux_kind(act_dtype, act),
+                       colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None,
+                       aux_kind=2 if u.dtype == torch.uint8 else _aux_kind(act_dtype, act),
                        defer=rq, pitched=bf)  # (dy c_proj)*act'(u), colsum
     dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)), defer=rq)) if need[11] else None
     dy2 = p_dgrad(du, wfc_c, act_dtype)

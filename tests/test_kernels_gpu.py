@@ -112,6 +112,31 @@ def test_gemm_saved_activation_derivative(dtype, M, N, K):
         ops.p_linear(x, w, b, act=ops.ACT_GELU_ERF, want_aux=True, aux_kind=1)
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(512, 512, 128, 0), (1024, 3072, 768, 512), (768, 2048, 512, 0)])
+def test_gemm_saved_derivative_one_byte(M, N, K, pad):
+    """aux_kind 2 (what the towers keep in bf16 mode on full 256 x 256 tiles): act'(u) as one byte per element,
+    q = rint((act' + 0.125) * 204): the forward output is unchanged, the decoded derivative is within half a step (1/408)
+    of the bf16 one, and the act' data gradient multiplies by the decoded value; pitched outputs; ragged shapes refuse."""
+    x, w, b = rnd(M, K, dtype=BF, seed=61), rnd(N, K, dtype=BF, seed=62, scale=K ** -0.5), rnd(N, seed=63)
+    pre = x.float() @ w.float().t() + b
+    sg = torch.sigmoid(1.702 * pre)
+    dref = sg * (1 + 1.702 * pre * (1 - sg))
+    y1, a1 = ops.p_linear(x, w, b, act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=1)
+    y2, a2 = ops.p_linear(x, w, b, act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=2, pitched=pad > 0)
+    assert a2.dtype == torch.uint8 and a2.shape == (M, N)
+    assert torch.equal(y1, y2)
+    dec = a2.float() / 204.0 - 0.125
+    assert float((dec - dref).abs().max()) <= 0.5 / 204.0 + 2e-2 * 0.02 + 4e-3   # half a step + the bf16 accumulate noise of pre
+    assert float((dec - a1.float()).abs().max()) <= 0.5 / 204.0 + 5e-3
+    g, w2 = rnd(M, K, dtype=BF, seed=64), rnd(K, N, dtype=BF, seed=65, scale=K ** -0.5)
+    du2, cs = ops.p_dgrad(g, w2, BF, aux=a2, act=ops.ACT_QUICK_GELU, aux_kind=2, want_colsum=True, pitched=pad > 0)
+    ref = (g.float() @ w2.float()) * dec
+    close(du2, ref, 2e-2, 2e-2, "dgrad * decoded derivative")
+    close(cs, du2.float().sum(0), 2e-3, 2e-2 * M ** 0.5, "fused column sums")
+    with pytest.raises(RuntimeError):       # not a multiple of the 256-wide tiles: the caller has to take aux_kind 1
+        ops.p_linear(x[:200], w[:136], b[:136], act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=2)
+
+
 def test_gemm_bf16_fp32_A_operand_and_splitk():
     """fp32 residual-stream gradients as the A operand of the bf16 kernels; split-K wgrad (M >> tiles)."""
     M, N, K = 6272, 256, 128
