@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_p8_kernel(Args g) {
   // their store phase at the same moment in every later round (kept from gemm_bf16_dma.hip, where it measured +5..10 %).
   if (!(g.touch & 2) && bid < 256 && gridDim.x * gridDim.y * gridDim.z > 256) {
     const long long t_tile = (long long)nk * 3000 + 20000;
-    const long long cap = (long long)(g.touch >> 2);          // first-round stagger unit cap in cycles (default 5000)
+    const long long cap = (long long)(g.touch >> 2);          // first-round stagger unit cap in cycles (default 2000)
     const long long unit = t_tile / 8 < cap ? t_tile / 8 : cap;
     // tiles of one block row share their A rows through the XCD's L2: they get the SAME delay and stay in lockstep
     const long long wait = (trow & 7) * unit;
@@ -539,7 +539,7 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   if ((a_ks ? 64 : 256) * (a_ks ? d->sak : d->sam) * 2 >= (int64_t)1 << 31) return false;
   if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
   static const int touch = [] { const char* e = getenv("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
-  static const int stagger = [] { const char* e = getenv("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 5000; }();   // unit cap in cycles; 0 = off
+  static const int stagger = [] { const char* e = getenv("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 2000; }();   // unit cap in cycles; 0 = off.  In the step (two runs each): 5000: 43.74 ms, 2000: 43.50, 1000: 43.47, 0: 43.47, 12000: 43.98
   static const int epi_abl = [] { const char* e = getenv("SEGCLIP_P8_EPI_ABL"); return e ? atoi(e) : 0; }();
   g.abl = epi_abl;
   g.touch = (touch ? 1 : 0) | (stagger > 0 ? 0 : 2) | (stagger << 2);   // bit 0: side-tile touch experiment, bit 1: no first-round stagger
