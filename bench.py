@@ -55,9 +55,18 @@ def parse():
     ap.add_argument("--grad-sync", default="segclip", choices=["segclip", "ddp"],
                     help="N>1 gradient exchange: segclip_amd.dist.GradSync (default) or torch DDP (comparison only)")
     ap.add_argument("--attn-fp8", default="auto", choices=["auto", "on", "off"],
-                    help="e4m3 MFMA for QK^T / PV in the self-attention forward (auto: on for --spec vitl14_336 = configs[4])")
+                    help="e4m3 MFMA for QK^T / PV in the self-attention forward.  auto = off: at head_dim 64 the non-scaled e4m3 "
+                         "MFMA runs at the bf16 rate and the quantisation passes make the step slower (1281 vs 1308 pairs/s on "
+                         "configs[4], profiles/r03_bench_configs.json); `on` keeps the configs[4] switch reachable")
     ap.add_argument("--text-after-blocks", type=int, default=-1, help="config.text_after_blocks override (launch order of the towers)")
     ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format (auto = fp32, what the reference DDP exchanges; bf16 is an opt-in)")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="N>1: cap (and floor) the RCCL channel count = the CUs the collective kernels take from the 256-CU GEMMs "
+                         "(sets NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS before the communicator is created; 0 = RCCL's own choice)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N>1 path.  gloo + --share-gpu exist for the single-GPU test of this script's "
+                         "own N>1 control flow (RCCL refuses two ranks on one device); numbers from it are not RCCL numbers")
+    ap.add_argument("--share-gpu", action="store_true", help="map rank r to device r %% visible devices (tests only)")
     return ap.parse_args()
 
 
@@ -192,13 +201,9 @@ def child_argv(a, steps, warmup):
 PEAK_HBM_GBS = 8000.0
 
 
-def roofline_block(a, step, pairs_per_gpu, world):
-    """Roofline of the kernel classes that carry the step, from KERNEL time: this command's per-GPU workload is run again
-    for a few steps as a child under `rocprofv3 --kernel-trace --stats` (and under two counters-only --pmc passes for the
-    HBM bytes of the dominant kernel); the algorithmic flops / bytes of each class are counted by the op layer during one
-    pass of the parent.  The towers run on two streams, so class times may overlap each other (their sum exceeds the step
-    time); a class time is the sum of its kernels' own durations, exactly what `rocprofv3 --stats` prints."""
-    from tools import rocprof_roofline as rr
+def count_step_work(step):
+    """{kernel class: [launches, flops, bytes]} of one step, counted by the op layer.  Runs one step: at N>1 EVERY rank
+    must call it (the step's collectives)."""
     ops._OpCount.start()
     step()
     torch.cuda.synchronize()
@@ -206,6 +211,17 @@ def roofline_block(a, step, pairs_per_gpu, world):
     for kind, fl, nb in ops._OpCount.stop():
         w = work.setdefault(kind, [0, 0.0, 0.0])
         w[0] += 1; w[1] += fl; w[2] += nb
+    return work
+
+
+def roofline_block(a, step, pairs_per_gpu, world, work, collective_free=True):
+    """Roofline of the kernel classes that carry the step, from KERNEL time: this command's per-GPU workload is run again
+    for a few steps as a child under `rocprofv3 --kernel-trace --stats` (and under two counters-only --pmc passes for the
+    HBM bytes of the dominant kernel); the algorithmic flops / bytes of each class (`work`) are counted by the op layer
+    during one pass of the parent.  The towers run on two streams, so class times may overlap each other (their sum
+    exceeds the step time); a class time is the sum of its kernels' own durations, exactly what `rocprofv3 --stats` prints.
+    collective_free=False (N>1: only rank 0 is here): nothing in this function may run a model step."""
+    from tools import rocprof_roofline as rr
     step_frac = (round(pairs_per_gpu * GF_PER_PAIR[(a.spec, a.full_loss)] / 1e3 / PEAK_BF16_TF, 4)
                  if (a.spec, a.full_loss) in GF_PER_PAIR else None)
     ksteps, kwarm = 4, 2
@@ -214,7 +230,8 @@ def roofline_block(a, step, pairs_per_gpu, world):
         m = rr.measure(child_argv(a, ksteps, kwarm), ksteps + kwarm,
                        pmc_argv=None if a.no_traffic else child_argv(a, 1, 1), keep_dir=keep, timeout=600)
     except Exception as e:
-        return roofline_fallback(a, step, step_frac, f"rocprofv3 child not usable here ({type(e).__name__}: {str(e)[:200]})")
+        return roofline_fallback(a, step if collective_free else None, step_frac, work,
+                                 f"rocprofv3 child not usable here ({type(e).__name__}: {str(e)[:200]})")
     cl = m["classes"]
     if keep:
         with open(os.path.join(keep, "kernel_stats.txt"), "w") as f:
@@ -242,7 +259,7 @@ def roofline_block(a, step, pairs_per_gpu, world):
 
     g = mfma("gemm_bf16", "gemm_bf16")
     if g is None:
-        return roofline_fallback(a, step, step_frac, "no bf16 GEMM dispatch in the rocprofv3 trace")
+        return roofline_fallback(a, step if collective_free else None, step_frac, work, "no bf16 GEMM dispatch in the rocprofv3 trace")
     n, fl, nb = work["gemm_bf16"]
     classes = {"gemm_bf16": g, "attention_fwd": mfma("attn_fwd", "attn_fwd"), "attention_bwd": mfma("attn_bwd", "attn_bwd"),
                "layernorm_bwd": hbm("ln_bwd", "ln_bwd"), "layernorm_fwd": hbm("ln_fwd", "ln_fwd")}
@@ -263,9 +280,18 @@ def roofline_block(a, step, pairs_per_gpu, world):
             "classes": classes, "step_frac": step_frac, "notes": m["notes"]}
 
 
-def roofline_fallback(a, step, step_frac, why):
+def roofline_fallback(a, step, step_frac, work, why):
     """HIP-event timing of every bf16 GEMM launch with the towers SERIALISED (one stream: an event interval is then the
-    kernel's own time plus its dispatch gap) - used only where rocprofv3 cannot be started."""
+    kernel's own time plus its dispatch gap) - used only where rocprofv3 cannot be started.  step=None (N>1, where a step
+    on rank 0 alone would hang in its collectives): no kernel-level number, the step-level fraction only."""
+    if step is None:
+        n, fl, nb = work.get("gemm_bf16", [0, 0.0, 0.0])
+        return {"bound": "mfma", "kernel": "bf16 GEMM kernels, all launches of a step", "achieved": None, "peak": PEAK_BF16_TF,
+                "unit": "TFLOP/s", "frac": None, "traffic": None, "launches_per_step": n,
+                "algorithmic_flops_per_launch": round(fl / n) if n else None,
+                "algorithmic_bytes_per_launch": round(nb / n) if n else None,
+                "source": "FALLBACK at N>1: no kernel-time measurement (" + why + "); step_frac is the whole-step fraction",
+                "step_frac": step_frac}
     segclip_amd.config.overlap_towers = False
     step()
     ops._GemmProfile.start()
@@ -291,7 +317,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         n_dev = torch.cuda.device_count()
-        if n_dev < a.gpus:
+        if n_dev < a.gpus and not a.share_gpu:
             raise SystemExit(f"--gpus {a.gpus} but only {n_dev} GPU(s) visible")
         respawn(a)
     if a.gpus != world:
@@ -300,18 +326,25 @@ def main():
         if a.global_batch % world:
             raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} ranks")
         a.batch = a.global_batch // world
+    if a.share_gpu:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or a.force_dist
     if multi:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if a.rccl_channels > 0:   # before the communicator exists: RCCL reads these when it builds its rings
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(a.rccl_channels)
+        # the other ranks wait at the final barrier while rank 0 runs its rocprofv3 children (minutes): a long timeout
+        kw = dict(device_id=dev) if a.backend == "nccl" else {}
+        dist.init_process_group(a.backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60), **kw)
     spec = synth.SPECS[a.spec]
     flags = dict(use_seglabel=True, use_vision_mae_recon=True) if a.full_loss else {}
     segclip_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
-    attn_fp8 = a.dtype == "bf16" and (a.attn_fp8 == "on" or (a.attn_fp8 == "auto" and a.spec == "vitl14_336"))
+    attn_fp8 = a.dtype == "bf16" and a.attn_fp8 == "on"
     segclip_amd.config.attn_fp8 = attn_fp8
     if a.text_after_blocks >= 0:
         segclip_amd.config.text_after_blocks = a.text_after_blocks
@@ -367,8 +400,13 @@ def main():
     pairs = a.batch * world * a.steps / elapsed
 
     roofline = None
-    if not a.no_roofline and a.dtype == "bf16" and rank == 0:
-        roofline = roofline_block(a, step, pairs / world, world)
+    if not a.no_roofline and a.dtype == "bf16":
+        # EVERY rank runs the op-count pass (one more step: its collectives must be matched on all ranks - ADVICE r3: with
+        # rank 0 alone in it, rank 0 hung in the embedding all-gather / bucket all-reduces); only rank 0 starts the
+        # rocprofv3 children, which run this rank's per-GPU workload as a single-GPU process (no collectives)
+        work = count_step_work(step)
+        if rank == 0:
+            roofline = roofline_block(a, step, pairs / world, world, work, collective_free=world == 1)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -387,15 +425,20 @@ def main():
                                        if a.full_loss else
                                        "BASELINE configs[1]/[2]: ViT-B/16 224^2 + 77-token text, contrastive loss only"),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                          "attention_forward": ("fp8 e4m3 MFMA (QK^T, PV), per-token Q/K scales" if attn_fp8 else a.dtype),
+                          "attention_forward": ("fp8 e4m3 MFMA (QK^T, PV), per-token Q/K scales" if attn_fp8 else
+                                                a.dtype + (" (--attn-fp8 auto = off: the non-scaled e4m3 MFMA has the bf16 rate and its "
+                                                           "quantisation passes cost more than they save at head_dim 64)"
+                                                           if a.spec == "vitl14_336" and a.attn_fp8 == "auto" else "")),
                           "grad_exchange": (None if not multi else "torch DDP fp32" if a.grad_sync == "ddp" else
                                             f"GradSync {len(net._flat)} buckets, wire " +
                                             ("bf16" if net._flat and net._use_bf16(net._flat[0]) else "fp32") +
-                                            f", zero-copy grads {net.stats['zero_copy']}/{net.stats['zero_copy'] + net.stats['copies']}"),
+                                            f", zero-copy grads {net.stats['zero_copy']}/{net.stats['zero_copy'] + net.stats['copies']}"
+                                            f", backend {a.backend}, RCCL channels {a.rccl_channels or 'default'}"),
                           "cross_mode": segclip_amd.config.cross_mode, "loss": round(loss_val, 5)},
                "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if multi:
+        dist.barrier()   # nobody tears the group down while another rank may still be inside a collective
         dist.destroy_process_group()
 
 

@@ -32,6 +32,13 @@ for part in $parts; do
     pids+=($!)
   fi
 done
+for part in 0 1 2; do   # persistent 256x256 kernel (gemm_bf16_pq.hip): forward layout, data-gradient layout, dispatcher
+  f=gemm_bf16_pq.hip; o=build/gemm_bf16_pq_part$part.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
+    throttle; $HIPCC $FLAGS -DPQ_PART=$part -c $f -o $o &
+    pids+=($!)
+  fi
+done
 rm -f build/gemm_bf16_dma.o
 for part in 0 1 2 3 4; do
   f=gemm_bf16_dma.hip; o=build/gemm_bf16_dma_part$part.o

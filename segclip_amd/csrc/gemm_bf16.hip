@@ -366,6 +366,7 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args, int
                                hipStream_t stream);
 bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t kper, int64_t nb,
                               hipStream_t stream);
+bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args, int splits, int64_t nb, hipStream_t stream);
 int segclip_gemm_bf16_dma_pick_bn(const segclip_gemm_desc* d, int64_t nbatch_splits);
 
 static bool aligned16(const segclip_gemm_desc* d) {
@@ -481,8 +482,12 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
     // 256x256 tiles: the phase-pipelined kernel (gemm_bf16_p8.hip); 256x128 / 128x128 tiles: the one-barrier-per-K-tile
     // kernel (gemm_bf16_dma.hip)
-    if (force_tile == 0 && segclip_gemm_bf16_dma_pick_bn(d, nb * g.splits) == 256)
-      launched = segclip_gemm_bf16_p8_try(d, &g, g.splits, g.kper, nb, stream);
+    // 256x256 tiles, bf16 output, full tiles, no split-K: the persistent kernel with the overlapped output path
+    // (gemm_bf16_pq.hip); else the phase-pipelined one-tile-per-workgroup kernel (gemm_bf16_p8.hip)
+    if (force_tile == 0 && segclip_gemm_bf16_dma_pick_bn(d, nb * g.splits) == 256) {
+      launched = segclip_gemm_bf16_pq_try(d, &g, g.splits, nb, stream);
+      if (!launched) launched = segclip_gemm_bf16_p8_try(d, &g, g.splits, g.kper, nb, stream);
+    }
     if (!launched) launched = segclip_gemm_bf16_dma_try(d, &g, g.splits, g.kper, nb, stream);
   }
   if (d->colsum && (!launched || !g.colsum_part)) {

@@ -36,6 +36,12 @@ from torch import nn
 
 _ALIGN = 64  # slot alignment in fp32 elements (256 bytes)
 _NO_EXCHANGE = bool(int(os.environ.get("SEGCLIP_GRADSYNC_NOEXCHANGE", "0")))  # diagnosis: hooks + slots, no collective
+# The cross-rank agreement on late gradients (a parameter that starts receiving a gradient after the bucket layout was
+# frozen) costs an all-reduce + a blocking host read per backward: it runs in the first _CHECK_PASSES steady passes
+# (where a data-dependent graph would show up) and, with SEGCLIP_CHECK_COLLECTIVES=1, in every pass.  Afterwards a late
+# gradient raises on the rank that sees it (no host synchronisation in the steady-state path).
+_CHECK_ALWAYS = bool(int(os.environ.get("SEGCLIP_CHECK_COLLECTIVES", "0")))
+_CHECK_PASSES = int(os.environ.get("SEGCLIP_CHECK_COLLECTIVES_PASSES", "2"))
 
 
 class _Slot:
@@ -101,7 +107,8 @@ class GradSync(nn.Module):
         self._bstreams = []          # per bucket: the streams its gradients were produced on in this pass
         self._comm = None
         self._pass_id = 0
-        self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0}
+        self._steady_passes = 0      # synced backward passes since the layout was frozen
+        self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0, "verdicts": 0}
         self._accumulated = False    # a no_sync() backward left local gradients in the buckets
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
         if broadcast_init and self.world > 1:
@@ -265,14 +272,22 @@ class GradSync(nn.Module):
                             self._slots[i].view().zero_()
                             p.grad = self._slots[i].view()
                 self._exchange(b)
-            if dist.is_initialized() and self.world > 1:
-                # the number of late exchanges must be the same on every rank (data-dependent use): agree first, raise
-                # everywhere instead of hanging in mismatched collectives
-                dev = self._flat[0].device if self._flat else torch.device("cpu")
-                n = torch.tensor([len(self._late), -len(self._late)], dtype=torch.int64, device=dev)
-                dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
-                if int(n[0]) != -int(n[1]):
-                    raise RuntimeError("GradSync: ranks disagree on the parameters that received late gradients")
+            if dist.is_initialized():   # also a 1-rank group (bench.py --force-dist): the same branch structure as N > 1
+                self._steady_passes += 1
+                if _CHECK_ALWAYS or self._steady_passes <= _CHECK_PASSES:
+                    # the number of late exchanges must be the same on every rank (data-dependent use): agree first,
+                    # raise everywhere instead of hanging in mismatched collectives.  Blocking host read: first passes only.
+                    dev = self._flat[0].device if self._flat else self._params[0].device
+                    n = torch.tensor([len(self._late), -len(self._late)], dtype=torch.int64, device=dev)
+                    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+                    self.stats["verdicts"] += 1
+                    if int(n[0]) != -int(n[1]):
+                        raise RuntimeError("GradSync: ranks disagree on the parameters that received late gradients")
+                elif self._late:
+                    raise RuntimeError(
+                        f"GradSync: {len(self._late)} parameter(s) received a gradient for the first time after the bucket "
+                        "layout was frozen (data-dependent graph); run with SEGCLIP_CHECK_COLLECTIVES=1 to exchange such "
+                        "gradients under a per-pass cross-rank agreement")
             for p in self._late:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
                 p.grad.div_(self.world)

@@ -1243,6 +1243,33 @@ def mask_sort(noise, len_keep):
     return ids_shuffle, ids_restore, mask
 
 
+class _on_comm_stream:
+    """The embedding exchange runs on the communication stream (the one GradSync's bucket all-reduces use), ordered
+    against the compute stream by events on both sides instead of being enqueued in-line on it: RCCL's launch-side
+    bookkeeping then never sits between two compute kernels, and the collective keeps its own hardware queue."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __enter__(self):
+        if not self.t.is_cuda:      # CPU tensors (gloo tests): nothing to order
+            self.ctx = None
+            return
+        from . import streams
+        self.main = torch.cuda.current_stream(self.t.device)
+        self.comm = streams.side_stream("comm", self.main)
+        self.comm.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.comm)
+        self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is None:
+            return False
+        self.ctx.__exit__(*exc)
+        self.main.wait_stream(self.comm)   # the consumer (logits GEMM) follows at once: no allocator hand-over needed
+        return False
+
+
 class AllGatherFn(Function):
     """Differentiable rank-ordered all-gather of (B, ...) embeddings (dist_collect,
     modules/util_module.py:180-190; diffdist semantics: all_gather forward, reduce-scatter(SUM)
@@ -1264,7 +1291,8 @@ class AllGatherFn(Function):
             dist.all_reduce(out, op=dist.ReduceOp.SUM)
             return out
         out = torch.empty((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x)
+        with _on_comm_stream(x):
+            dist.all_gather_into_tensor(out, x)
         return out
 
     @staticmethod
@@ -1275,7 +1303,8 @@ class AllGatherFn(Function):
         n = g.shape[0] // ctx.world
         if dist.get_backend() == "nccl":
             out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
+            with _on_comm_stream(g):
+                dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
             return out
         g = g.clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM)

@@ -176,3 +176,50 @@ def test_gradsync_broadcasts_initial_state_and_raises_on_every_rank(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_worker_init, args=(2, _free_port(), out), nprocs=2, join=True)
     assert all(os.path.exists(f"{out}.{r}") for r in range(2))
+
+
+class LateToy(nn.Module):
+    """`late` joins the graph only when use_late is set: a data-dependent graph after the layout was frozen."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(9)
+        self.a = nn.Parameter(torch.randn(4, 3, generator=g))
+        self.late = nn.Parameter(torch.randn(3, generator=g))
+        self.use_late = False
+
+    def forward(self, x):
+        y = (x @ self.a.t()).pow(2).mean()
+        return y + (x * self.late).sum() if self.use_late else y
+
+
+def _verdict_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segclip_amd import dist as sd
+    net = sd.GradSync(LateToy())
+    x = torch.randn(6, 3, generator=torch.Generator().manual_seed(rank))
+    for step in range(6):   # step 0 builds the layout; the agreement all-reduce runs in the first _CHECK_PASSES steady passes only
+        net.zero_grad(set_to_none=True)
+        net(x).backward()
+    assert net.stats["verdicts"] == sd._CHECK_PASSES, net.stats
+    # steady state: a late gradient raises on the rank that sees it instead of walking into an unmatched collective
+    net.module.use_late = True
+    net.zero_grad(set_to_none=True)
+    try:
+        net(x).backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "after the bucket layout was frozen" in str(e)
+    assert raised
+    torch.save(True, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_gradsync_late_gradient_agreement_only_in_the_first_passes(tmp_path):
+    """no all-reduce + blocking host read per backward in the steady state."""
+    out = str(tmp_path / "ok")
+    mp.spawn(_verdict_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert all(os.path.exists(f"{out}.{r}") for r in range(2))

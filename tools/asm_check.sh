@@ -4,6 +4,7 @@
 set -e
 f=$(realpath "$1"); b=$(basename "$f" .hip); shift
 extra="$*"; case "$b" in gemm_bf16_p8) case "$extra" in *P8_PART*) ;; *) extra="$extra -DP8_PART=0";; esac;;
+  gemm_bf16_pq) case "$extra" in *PQ_PART*) ;; *) extra="$extra -DPQ_PART=0";; esac;;
   gemm_bf16) case "$extra" in *GB_PART*) ;; *) extra="$extra -DGB_PART=0";; esac;;
   gemm_bf16_dma) case "$extra" in *DMA_PART*) ;; *) extra="$extra -DDMA_PART=0";; esac;; esac
 mkdir -p /tmp/asm/$b && cd /tmp/asm/$b
