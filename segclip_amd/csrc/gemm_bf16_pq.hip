@@ -1,28 +1,33 @@
-// bf16 MFMA GEMM, 256x256x64 tiles, PERSISTENT workgroups with an overlapped output path (round 4).
+// bf16 MFMA GEMM, 256x256x64 tiles, accumulators in the accumulator register file, transposed result blocks and a
+// packed-bf16 output path (round 4).  Takes over from gemm_bf16_p8.hip the shapes that carry the training step:
+// C(m,n) = epi(sum_k A(m,k) B(n,k)), A bf16 k-contiguous, B bf16 k-contiguous (forward, weights (N,K)) or k-strided (data
+// gradient, weights (K,N) read as B(n,k) = W[k][n]), C bf16, M and N multiples of 256, K a multiple of 64, no split-K, no
+// batch.  The K loop is the 8-phase LDS-DMA ring of gemm_bf16_p8.hip (see there for the schedule); new is the rest:
 //
-// Same contract as gemm_bf16_p8.hip for the shapes it takes: C(m,n) = epi(sum_k A(m,k) B(n,k)), A bf16 k-contiguous,
-// B bf16 k-contiguous (forward, weights (N,K)) or k-strided (data gradient, weights (K,N) read as B(n,k) = W[k][n]),
-// C bf16, M and N multiples of 256, K a multiple of 64, no split-K, no batch.  The K loop is the 8-phase LDS-DMA ring of
-// gemm_bf16_p8.hip (see there for the schedule); what is new is everything around it:
-//
-//  * The accumulators live in the ACCUMULATOR half of the unified register file (a[0:127]) and are only touched by inline
-//    asm (v_mfma ... a[..], v_accvgpr_read): hipcc never sees 128 live accumulator values, so the tile loop that encloses
-//    the K loop costs no spills (three attempts with compiler-managed accumulators ended with 30-70 spill reloads inside
-//    the K loop).  With 2 waves per SIMD the budget is 128 architectural + 128 accumulator registers.
-//  * The MFMA operands are SWAPPED (srcA = B fragment, srcB = A fragment): the 32x32 result block is then held transposed,
-//    lane = output ROW, 16 registers = 4 groups of 4 CONSECUTIVE columns.  bf16 pairs are packed in-lane
+//  * The 128 accumulators live in a[0:127] and are only touched by inline asm (v_mfma ... a[..], v_accvgpr_read): hipcc
+//    sees a kernel with ~100 live registers, compiles it in seconds instead of minutes and spills nothing (the compiler-
+//    managed form of gemm_bf16_p8.hip sits at 256 VGPRs with 31 spilled).  Budget with 2 waves per SIMD: 128 + 128.
+//  * The MFMA operands are SWAPPED (srcA = B fragment, srcB = A fragment): the 32x32 result block is held transposed,
+//    lane = output ROW, 16 registers = 4 groups of 4 CONSECUTIVE columns.  Everything elementwise (bias, QuickGELU and
+//    its saved derivative, act' multiplier) happens in that layout in fp32; bf16 pairs are packed in-lane
 //    (v_cvt_pk_bf16_f32 on adjacent registers, no lane exchange) and a group leaves as ONE ds_write_b64.
-//  * Epilogue = four QUADRANTS (128 x 128) through one 32-KiB bf16 patch (the LDS the 128-KiB ring leaves free),
-//    XOR-swizzled so that parking (ds_write_b64) and the row pass (ds_read_b128, then 16-byte stores of whole 256-byte
-//    row segments) are both conflict-free: 32 + 16 LDS instructions per wave and tile instead of 128 + 32, half the bytes.
-//  * A workgroup walks a static list of tiles (its XCD's contiguous chunk of the tile sequence, so the 32 workgroups
-//    of an XCD always work on neighbouring tiles) and issues the NEXT tile's first 7 half-tile DMAs before it starts the
-//    epilogue of the current one: the load round trip, the workgroup turnaround and the store drain overlap.
-//    vmcnt is one in-order counter for loads and stores: the counted waits of the K loop stay correct (they are only
-//    more conservative while output stores are still in flight).
+//  * Output = two HALVES (128 rows) of two QUADRANTS (128 x 128) each, parked as bf16 in XOR-swizzled 32-KiB patches
+//    (conflict-free ds_write_b64 on the way in, ds_read_b128 on the way out) and stored as whole 128-byte lines: 32 + 16
+//    LDS instructions per wave and tile instead of 128 + 32 on fp32 data, 3 workgroup barriers instead of 12.
+//  * Side operands never occupy registers during the K loop: the bias (256 B per wave) and the saved-derivative bytes of the
+//    first half travel by LDS-DMA into the 32 KiB the ring leaves free, the second half's follow into ring space once the
+//    K loop is over; they are re-read in the accumulator layout with ds_read.
 //
-// Epilogue modes: PQ_PLAIN (bias), PQ_RES (bias + bf16 residual), PQ_ACT8 (bias, QuickGELU, saved derivative as one byte),
-// PQ_DACT8 (* saved derivative, + column sums of the output).  Side operands are read in the accumulator layout.
+// Measured (MI355X, M = 50176, tools/bench_pq.py, bit-identical outputs): forward N = 2304, K = 768 195 -> 158 us, data
+// gradients 4-9 % faster than gemm_bf16_p8.hip; per tile (tools/debug/pq_ksweep.py): K loop 1.43 us per K-tile, fixed cost
+// 1.5 us + output VALU/LDS 1.4 us + output stores 2.0-2.3 us (8-phase kernel: 5.9 us of output path).
+// A PERSISTENT form of this kernel (static tile walk per XCD, the next tile's first 7 half-tile DMAs issued before the
+// epilogue, the K loop's counted waits extended past the 16 output stores: vmcnt(26)) was built and measured first
+// (git history: dc78ad3): bit-exact, and NOT faster than one tile per workgroup (N = 2304, K = 768: 153.8 vs 155.8 us;
+// in the training step 43.23 vs 43.33 ms): with the epilogue removed both forms take the same 130 us, i.e. the
+// workgroup turnaround was never exposed, and the output stores cost their 2 us per tile as memory-system throughput
+// wherever they are issued (the same time with and without counted waits past them).  The one-tile form keeps the
+// hardware's dynamic workgroup scheduling, which the two concurrent towers rely on, and frees the whole ring for the output.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -35,9 +40,14 @@ constexpr int BK = 64, BT = 256, NWV = 8;
 constexpr int UNIT = 128 * BK * 2;            // one half-tile: 16 KiB
 constexpr int BUF = 4 * UNIT;                 // A0 A1 B0 B1
 constexpr int RING = 2 * BUF;                 // 128 KiB
-constexpr int PATCH = RING;                   // byte offset of the epilogue patch
-constexpr int PATCH_BYTES = 32768;            // one quadrant, bf16
-constexpr int LDS_BYTES = RING + PATCH_BYTES; // 160 KiB
+constexpr int EXTRA = RING;                   // 32 KiB beyond the ring: free during the K loop
+constexpr int LDS_BYTES = RING + 32768;       // 160 KiB
+// epilogue map (the ring is free by then)
+constexpr int H_OFF = 0;                      // bf16 output patches of the current half: J * 32 KiB
+constexpr int AO_OFF = 65536;                 // uint8 saved-derivative patches (PQ_ACT8): J * 16 KiB
+constexpr int SI1_OFF = 98304;                // side-in of the second half (PQ_DACT8: uint8, J * 16 KiB)
+constexpr int SI0_OFF = EXTRA;                // side-in of the first half, fetched during the K loop
+constexpr int BIAS_OFF = EXTRA;               // bias: wave * 256 B (modes with a bias have no side-in)
 
 enum { PQ_PLAIN = 0, PQ_RES = 1, PQ_ACT8 = 2, PQ_DACT8 = 3 };
 
@@ -57,7 +67,10 @@ typedef __attribute__((address_space(3))) const char lds_cchar;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) const bf16x8_t lds_bf16x8;
 typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 
 #define PQ_AGPRS                                                                                                          \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17",     \
@@ -87,7 +100,9 @@ template <int B> __device__ __forceinline__ void acc_read8(float* v) {
       : "i"(B), "i"(B + 1), "i"(B + 2), "i"(B + 3), "i"(B + 4), "i"(B + 5), "i"(B + 6), "i"(B + 7));
 }
 
-// Two LDS-DMA pieces (1 KiB each) of one half-tile; see gemm_bf16_p8.hip (inline asm: hidden from hipcc's waitcnt pass).
+// LDS-DMA pieces, issued from INLINE ASM (hidden from hipcc's waitcnt pass, see gemm_bf16_p8.hip).  Nothing here has a
+// VGPR destination: an asm load into registers lets hipcc copy those registers before the data has landed.
+//   s_nop 4: SGPR base written by SALU -> read by VMEM; s_nop 0: M0 written by SALU -> read by the LDS-DMA.
 __device__ __forceinline__ void dma16x2(const char* base_uniform, uint32_t off0, uint32_t off1, uint32_t lds0) {
   asm volatile(
       "s_nop 4\n\t"
@@ -100,6 +115,12 @@ __device__ __forceinline__ void dma16x2(const char* base_uniform, uint32_t off0,
       :
       : "v"(off0), "v"(off1), "s"(base_uniform), "s"(lds0)
       : "memory", "scc");
+}
+__device__ __forceinline__ void dma16(const void* base_uniform, uint32_t off, uint32_t lds0) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base_uniform), "s"(lds0) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* base_uniform, uint32_t off, uint32_t lds0) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(off), "s"(base_uniform), "s"(lds0) : "memory");
 }
 
 // per-lane DMA source offsets (bytes from the tile's first element), as in gemm_bf16_p8.hip; full tiles only
@@ -143,7 +164,6 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -160,64 +180,127 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     PQ_BAR();                                                \
   } while (0)
 
-// 16-byte store of whole row segments, issued from inline asm (not on hipcc's vmcnt scoreboard: the epilogue's barriers and
-// the next K loop's counted waits must not turn into vmcnt(0)); s_nop 1: the data registers are read after issue
+// 16-byte store of whole lines, issued from inline asm (not on hipcc's vmcnt scoreboard: the waits between the halves are
+// counted by hand); s_nop 1: the data registers are read after issue
 __device__ __forceinline__ void store16_nt(const void* base_uniform, uint32_t off, const u32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base_uniform) : "memory");
 }
-__device__ __forceinline__ void store8_nt(const void* base_uniform, uint32_t off, const u32x2& v) {
-  asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base_uniform) : "memory");
-}
 
-// ---- one quadrant (I = A half, J = B half) of the tile: accumulators -> [bias, side operand, activation] -> bf16 patch
-// Accumulator layout (swapped MFMA): block (I, ri, J) = a[((I*2+ri)*2+J)*16 ..+15]; lane l holds row
+// ---- output path.  Accumulator layout (swapped MFMA): block (I, ri, J) = a[((I*2+ri)*2+J)*16 ..+15]; lane l holds row
 // I*128 + wr*64 + ri*32 + (l&31), register r column J*128 + wc*32 + 8*(r>>2) + 4*(l>>5) + (r&3).
-// Patch: [128 rows][256 B]; 16-byte chunk c of row R is stored at chunk c ^ (R&7), and its two 8-byte halves are swapped
-// when (R>>3)&1: the 16 lanes a ds_write_b64 services together (16 consecutive rows, one column group) hit 16 different
-// 8-byte slots of the 128-byte bank window.
+// bf16 patch of a quadrant: [128 rows][256 B]; 16-byte chunk c of row R is stored at chunk c ^ (R&7), and its two 8-byte
+// halves are swapped when (R>>3)&1: the 16 lanes a ds_write_b64 services together (16 consecutive rows, one column group)
+// hit 16 different 8-byte slots of the 128-byte bank window.
+// uint8 patch of a quadrant: [128 rows][128 B]; chunk c at c ^ (R&7) and (patches written by ds_write_b32) dword d of a
+// chunk at d ^ ((R>>3)&3): 32 rows x one dword -> 32 different banks.
 template <int MODE, int I, int J, int RI>
-__device__ __forceinline__ void pq_park_block(lds_char* sm, const f32x4 (&bias)[4], uint32_t base0, int x) {
+__device__ __forceinline__ void pq_block(const PQArgs& g, lds_char* sm, const f32x4 (&bias)[4], int li, int lk, int wr,
+                                         int wc, int si_off) {
   float v[16];
   acc_read8<((I * 2 + RI) * 2 + J) * 16>(v);
   acc_read8<((I * 2 + RI) * 2 + J) * 16 + 8>(v + 8);
+  const uint32_t hbase = H_OFF + J * 32768 + (uint32_t)(wr * 64 + RI * 32 + li) * 256 + ((((uint32_t)wc * 4) ^ (li & 4)) << 4) +
+                         ((lk ^ ((li >> 3) & 1)) << 3);
+  const uint32_t row128 = (uint32_t)(wr * 64 + RI * 32 + li) * 128;
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     float w[4];
+    // uint8 patches: byte column wc*32 + 8 gq + 4 lk -> chunk wc*2 + (gq>>1), dword (gq&1)*2 + lk
+    const uint32_t c8 = ((uint32_t)wc * 2 + (gq >> 1)) ^ (li & 7);
+    if constexpr (MODE == PQ_DACT8) {
+      const uint32_t q = *reinterpret_cast<lds_cu32*>(sm + si_off + J * 16384 + row128 + (c8 << 4) + (((gq & 1) * 2 + lk) << 2));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = v[gq * 4 + k] + bias[gq][k];
+      for (int k = 0; k < 4; ++k) {
+        const float qf = (float)((q >> (8 * k)) & 0xffu);   // v_cvt_f32_ubyteN
+        w[k] = v[gq * 4 + k] * (qf * (1.0f / AUX8_SCALE) - AUX8_OFF);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = v[gq * 4 + k] + bias[gq][k];
+    }
+    if constexpr (MODE == PQ_ACT8) {
+      uint32_t q = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float sd;
+        w[k] = act_with_side(SEGCLIP_ACT_QUICK_GELU, 1, w[k], &sd);
+        q = __builtin_amdgcn_cvt_pk_u8_f32((sd + AUX8_OFF) * AUX8_SCALE, k, q);
+      }
+      *reinterpret_cast<lds_u32*>(sm + AO_OFF + J * 16384 + row128 + (c8 << 4) +
+                                  ((((gq & 1) * 2 + lk) ^ ((li >> 3) & 3)) << 2)) = q;
+    }
     u32x2 p;
     p[0] = pack2bf(w[0], w[1]);
     p[1] = pack2bf(w[2], w[3]);
-    *reinterpret_cast<lds_u32x2*>(sm + base0 + RI * 8192 + ((gq ^ x) << 4)) = p;
+    *reinterpret_cast<lds_u32x2*>(sm + hbase + ((gq ^ (li & 3)) << 4)) = p;
   }
 }
-template <int MODE, int I, int J>
-__device__ __forceinline__ void pq_park(const PQArgs& g, lds_char* sm, const f32x4 (&bias)[4], int lane, int wr, int wc,
-                                        int64_t m0, int64_t n0) {
-  const int li = lane & 31, lk = lane >> 5;
-  const uint32_t base0 = PATCH + (uint32_t)(wr * 64 + li) * 256 + ((((uint32_t)wc * 4) ^ (li & 4)) << 4) +
-                         ((lk ^ ((li >> 3) & 1)) << 3);
-  pq_park_block<MODE, I, J, 0>(sm, bias, base0, li & 3);
-  pq_park_block<MODE, I, J, 1>(sm, bias, base0, li & 3);
-}
 
-// row pass of one quadrant: wave w moves rows w*16 .. w*16+15 of the patch (4 rows = 4 x 256 B per instruction)
-template <int I, int J>
-__device__ __forceinline__ void pq_rows(const PQArgs& g, lds_cchar* sm, int lane, int wave, const bf16_t* cq /* uniform: C + (m0 + I*128)*ldc + n0 + J*128 */) {
-  const int p = lane & 15, rs = lane >> 4;
-  const int c0 = p ^ rs;
-  const uint32_t rd = PATCH + (uint32_t)wave * 4096 + (uint32_t)lane * 16;
+// row pass of one half (two quadrants): wave w moves 64 rows x 64 columns (= one 128-byte line per row) of quadrant
+// J = w>>2: rows ((w>>1)&1)*64 .., columns (w&1)*64 ..; 8 rows per instruction.  A lane keeps ONE logical 16-byte chunk
+// over its 8 rows (the physical chunk c ^ (R&7) depends on lane>>3 only), so the column sums of the 64 rows are wave-local.
+template <int MODE, int I>
+__device__ __forceinline__ void pq_rows_half(const PQArgs& g, lds_cchar* sm, int lane, int wave, int64_t m0, int64_t n0) {
+  const int J = wave >> 2, rh = (wave >> 1) & 1, ch = wave & 1;
+  const int rs = lane >> 3, cl = lane & 7;
+  const int c = ch * 8 + cl;                                                    // logical chunk: columns c*8 .. +7
+  const uint32_t rd = H_OFF + J * 32768 + (uint32_t)(rh * 64 + rs) * 256 + ((uint32_t)(c ^ rs) << 4);
   const int64_t ldcb = g.ldc * 2;
-  const uint32_t o_even = (uint32_t)((wave * 16 + rs) * ldcb + c0 * 16);
-  const uint32_t o_odd = (uint32_t)((wave * 16 + rs) * ldcb + (c0 ^ 4) * 16);
+  const char* cq = reinterpret_cast<const char*>(g.C + (m0 + I * 128 + rh * 64) * g.ldc + n0 + J * 128);   // uniform
+  const uint32_t go = (uint32_t)(rs * ldcb + c * 16);
+  float cs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs[k] = 0.f;
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    u32x4 d[4];
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) d[i4] = *reinterpret_cast<lds_cu32x4*>(sm + rd + (h2 * 4 + i4) * 2048);
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int it = h2 * 4 + i4;                                               // rows it*8 + rs: bit 3 of the row = it & 1
+      if (it & 1) d[i4] = u32x4{d[i4][2], d[i4][3], d[i4][0], d[i4][1]};
+      if (MODE == PQ_DACT8 && g.colsum_part != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          cs[2 * k] += __uint_as_float(d[i4][k] << 16);
+          cs[2 * k + 1] += __uint_as_float(d[i4][k] & 0xffff0000u);
+        }
+      }
+      if (!(g.abl & 1)) store16_nt(cq + (int64_t)it * 8 * ldcb, go, d[i4]);
+    }
+  }
+  if (MODE == PQ_DACT8 && g.colsum_part != nullptr) {   // column sums of the stored (rounded) values over this wave's 64 rows
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float x = cs[k];
+      x += __shfl_xor(x, 8, 64);
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      cs[k] = x;
+    }
+    if (rs == 0) {
+      float* dst = g.colsum_part + ((m0 + I * 128 + rh * 64) >> 6) * g.N + n0 + J * 128 + c * 8;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+    }
+  }
+}
+// uint8 saved-derivative patches of one half -> global: wave w moves rows (w&3)*32 .. +31 of quadrant J = w>>2
+template <int I>
+__device__ __forceinline__ void pq_rows_aux(const PQArgs& g, lds_cchar* sm, int lane, int wave, int64_t m0, int64_t n0) {
+  const int J = wave >> 2, rb = (wave & 3) * 32;
+  const int rs = lane >> 3, pc = lane & 7;
+  const uint32_t rd = AO_OFF + J * 16384 + (uint32_t)rb * 128 + (uint32_t)lane * 16;
+  const char* aq = reinterpret_cast<const char*>(g.aux + (m0 + I * 128 + rb) * g.ldaux + n0 + J * 128);   // uniform
+  const uint32_t go = (uint32_t)(rs * g.ldaux + ((pc ^ rs) << 4));
   u32x4 d[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) d[it] = *reinterpret_cast<lds_cu32x4*>(sm + rd + it * 1024);
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    if (it & 2) d[it] = u32x4{d[it][2], d[it][3], d[it][0], d[it][1]};   // rows with bit 3 set keep their 8-byte halves swapped
-    const char* bq = reinterpret_cast<const char*>(cq) + (int64_t)it * 4 * ldcb;
-    if (!(g.abl & 1)) store16_nt(bq, (it & 1) ? o_odd : o_even, d[it]);
+  for (int it = 0; it < 4; ++it) {   // rows rb + it*8 + rs: (R>>3)&3 = it -> logical dword j sits at j ^ it
+    const u32x4 o = u32x4{d[it][0 ^ it], d[it][1 ^ it], d[it][2 ^ it], d[it][3 ^ it]};
+    if (!(g.abl & 1)) store16_nt(aq + (int64_t)it * 8 * g.ldaux, go, o);
   }
 }
 
@@ -229,21 +312,37 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   const int wr = wave >> 2, wc = wave & 3;
   int lane = tid & 63;
 
-  // ---- static unit walk: the tile sequence (row-major, columns fastest) is cut into 8 contiguous chunks, one per XCD
-  // (workgroup b runs on XCD b % 8); the workgroups of an XCD take the tiles of its chunk round-robin, so at any moment
-  // they work on up to 32 neighbouring tiles that share A row slabs / B column slabs through the XCD's L2.
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int nslot = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
-  const int q8 = g.ntiles >> 3, r8 = g.ntiles & 7;
-  const int cbeg = xcd * q8 + (xcd < r8 ? xcd : r8), clen = q8 + (xcd < r8 ? 1 : 0);
-  if (slot >= clen) return;
+  // workgroup b runs on XCD b % 8: the tile sequence (row-major, columns fastest) is cut into 8 contiguous chunks, one
+  // per XCD, so that the tiles sharing an A row slab / B column slab sit behind one L2 (as in gemm_bf16_p8.hip)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tcol = unit % g.nbx, trow = unit / g.nbx;
+  const int64_t m0 = (int64_t)trow * BT, n0 = (int64_t)tcol * BT;
+  const char* baseA = reinterpret_cast<const char*>(g.A + m0 * g.lda);
+  const char* baseB = reinterpret_cast<const char*>(B_KS ? g.B + n0 : g.B + n0 * g.ldb);
   const int nk = g.K / BK;
-  const bool slowwait = (g.abl & 4) != 0;   // experiment: keep the conservative vmcnt(10) waits behind an epilogue
   const int64_t stepA = BK * 2;
   const int64_t stepB = B_KS ? (int64_t)BK * g.ldb * 2 : BK * 2;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void*)smem);
 
-  // per-lane DMA offsets and fragment bases: functions of the lane and the leading dimensions only (tile-invariant)
+  // ---- side operands that travel during the K loop (oldest entries of the VM queue: the first counted wait covers them)
+  constexpr bool HAS_BIAS = MODE != PQ_DACT8;
+  const bool has_bias = HAS_BIAS && g.bias != nullptr;
+  if (has_bias)   // this wave's 2 x 32 columns: lane l -> column (l>>5)*128 + wc*32 + (l&31)
+    dma4(g.bias + n0 + wc * 32, (uint32_t)(((lane >> 5) * 128 + (lane & 31)) * 4), lds0 + BIAS_OFF + wave * 256);
+  // PQ_DACT8: saved-derivative bytes of one half (2 quadrants x [128 rows][128 B]) = 32 pieces of 1 KiB (8 rows each), 4 per
+  // wave; lane l of piece p: row (p&15)*8 + (l>>3), physical chunk l&7 <- logical chunk (l&7) ^ (row&7)
+  auto side_half = [&](int I, uint32_t dst) {
+    const char* sb = reinterpret_cast<const char*>(g.side) + (m0 + I * 128) * g.lds + n0;   // uniform
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave * 4 + i, J = p >> 4, r = (p & 15) * 8 + (lane >> 3);
+      dma16(sb, (uint32_t)(r * g.lds + J * 128 + (((lane & 7) ^ (r & 7)) << 4)), lds0 + dst + p * 1024);
+    }
+  };
+  if constexpr (MODE == PQ_DACT8) side_half(0, SI0_OFF);
+
   uint32_t offA[2][2], offB[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -252,7 +351,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
       offA[h][i] = off_direct(h, wave * 2 + i, lane, g.lda);
       offB[h][i] = B_KS ? off_ks(h, wave * 2 + i, lane, g.ldb) : off_direct(h, wave * 2 + i, lane, g.ldb);
     }
-  const uint32_t lds_ring = (uint32_t)(uintptr_t)((lds_void*)smem) + wave * 2048;
+  const uint32_t lds_ring = lds0 + wave * 2048;
   lds_cchar* const sm3 = (lds_cchar*)smem;
   lds_cchar* abase[2][4];
   lds_cchar* bbase[2][4];
@@ -269,28 +368,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
       bbase[bf][x] = sm3 + ob;
     }
 
-  auto stage = [&](const char* baseA, const char* baseB, int u, int t) {
+  auto stage = [&](int u, int t) {
     const uint32_t dst = lds_ring + (t & 1) * BUF + u * UNIT;
     if (u < 2) dma16x2(baseA + (int64_t)t * stepA, offA[u][0], offA[u][1], dst);
     else dma16x2(baseB + (int64_t)t * stepB, offB[u - 2][0], offB[u - 2][1], dst);
-  };
-  // first 7 half-tiles of a tile (K-tile 0 and, of K-tile 1, everything but A1, which R1 of K-tile 0 issues)
-  auto prologue = [&](const char* baseA, const char* baseB) {
-    stage(baseA, baseB, 2, 0);
-    stage(baseA, baseB, 0, 0);
-    stage(baseA, baseB, 3, 0);
-    stage(baseA, baseB, 1, 0);
-    if (nk > 1) {
-      stage(baseA, baseB, 2, 1);
-      stage(baseA, baseB, 0, 1);
-      stage(baseA, baseB, 3, 1);
-    }
-  };
-  auto tile_bases = [&](int unit, int64_t& m0, int64_t& n0, const char*& baseA, const char*& baseB) {
-    const int tcol = unit % g.nbx, trow = unit / g.nbx;
-    m0 = (int64_t)trow * BT; n0 = (int64_t)tcol * BT;
-    baseA = reinterpret_cast<const char*>(g.A + m0 * g.lda);
-    baseB = reinterpret_cast<const char*>(B_KS ? g.B + n0 : g.B + n0 * g.ldb);
   };
 
   bf16x8_t fa[2][4], fbx[4], fby[4];
@@ -329,124 +410,95 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  int64_t m0, n0;
-  const char *baseA, *baseB;
-  int iu = slot;
-  bool post_store = false;   // see ktile(): the previous epilogue's stores are still in the VM queue
-  tile_bases(cbeg + iu, m0, n0, baseA, baseB);
-  prologue(baseA, baseB);
-
-  while (true) {
-    // one K-tile: fbp holds B0(t) on entry and fbq is free; on exit fbq holds B0(t+1)
-    // ps: this tile follows an epilogue of this workgroup, whose PQ_NSTORE output stores sit in the VM queue BEHIND the 14
-    // prologue pieces issued before them.  vmcnt retires loads and stores in issue order, so the first six waits of the
-    // tile (K-tile 0 and R1 of K-tile 1, which retire exactly those 14 pieces) may leave the stores in flight as well:
-    // vmcnt(10 + 16).  From R2 of K-tile 1 on the retired piece is younger than the stores and the count is 10 again.
-    auto ktile = [&](auto bc, auto zc, int t, bool ps, bf16x8_t (&fbp)[4], bf16x8_t (&fbq)[4]) {
-      typedef decltype(bc) CB;
-      typedef integral_constant<int, 1 - CB::value> NB;
-      typedef decltype(zc) Z;
-      const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-      const bool ps0 = ps && t == 0, ps1 = ps && t <= 1;
-      auto wait_steady = [&](bool p) { if (p) wait_vm<26>(); else wait_vm<10>(); };
-      // ---- phase 1: quadrant (A0, B0)
-      read_a(CB{}, integral_constant<int, 0>{});
-      if (n1) { stage(baseA, baseB, 1, t + 1); wait_steady(ps1); } else { wait_vm<2>(); }          // retires B1(t), read in R2
-      PQ_BAR();
-      quadrant(I0{}, I0{}, Z{}, fbp);
-      PQ_BAR();
-      // ---- phase 2: quadrant (A0, B1)
-      read_b(CB{}, integral_constant<int, 3 * UNIT>{}, fbq);
-      if (n2) { stage(baseA, baseB, 2, t + 2); wait_steady(ps0); } else if (n1) { wait_vm<8>(); } else { wait_vm<0>(); }   // retires A1(t)
-      PQ_BAR();
-      quadrant(I0{}, I1{}, Z{}, fbq);
-      PQ_BAR();
-      // ---- phase 3: quadrant (A1, B1)
-      read_a(CB{}, integral_constant<int, UNIT>{});
-      if (n2) { stage(baseA, baseB, 0, t + 2); wait_steady(ps0); } else if (n1) { wait_vm<6>(); }   // retires B0(t+1), read in R4
-      PQ_BAR();
-      quadrant(I1{}, I1{}, Z{}, fbq);
-      PQ_BAR();
-      // ---- phase 4: quadrant (A1, B0); B1's registers are free: B0(t+1) goes there
-      if (n1) read_b(NB{}, integral_constant<int, 2 * UNIT>{}, fbq);
-      if (n2) { stage(baseA, baseB, 3, t + 2); wait_steady(ps0); } else if (n1) { wait_vm<4>(); }   // retires A0(t+1), read in R1
-      PQ_BAR();
-      quadrant(I1{}, I0{}, Z{}, fbp);
-      PQ_BAR();
-    };
-
-    if (post_store) wait_vm<26>(); else if (nk > 1) wait_vm<10>(); else wait_vm<4>();   // B0(0), A0(0) have landed
-    PQ_BAR();
-    read_b(I0{}, integral_constant<int, 2 * UNIT>{}, fbx);
-    if (wr == 1) PQ_BAR();     // group 1 runs one barrier interval behind group 0
-    ktile(I0{}, I1{}, 0, post_store, fbx, fby);     // first K-tile: the MFMAs overwrite the accumulators (C = 0)
-    int t = 1;
-    for (; t + 1 < nk; t += 2) {
-      ktile(I1{}, I0{}, t, post_store, fby, fbx);
-      ktile(I0{}, I0{}, t + 1, false, fbx, fby);
-    }
-    if (t < nk) ktile(I1{}, I0{}, t, false, fby, fbx);
-    if (wr == 0) PQ_BAR();     // group 0 catches up: every wave is done with the operand ring
-
-    // ---- the next tile's first DMA rounds go out before this tile's output
-    const int inext = iu + nslot;
-    const bool have_next = inext < clen;
-    const int64_t cm0 = m0, cn0 = n0;
-    asm volatile("" : "+v"(lane));   // lane-dependent epilogue addresses are re-derived per tile, not kept live across the K loop
-    const int li = lane & 31, lk = lane >> 5;
-    (void)li;
-    // bias: this wave's 2 x 32 columns travel by ONE 4-byte LDS-DMA instruction (no VGPR destination: a VGPR-destination asm
-    // load let hipcc copy the registers before the data had landed) into a wave-private 256-byte slot of the ring's A1 unit
-    // of buffer 1 - the one half-tile slot the next tile's prologue leaves alone - and is the oldest entry of the VM queue
-    // when the prologue pieces follow it; the L2 round trip passes under their issue time.
-    const bool has_bias = g.bias != nullptr && MODE != PQ_DACT8;
-    constexpr uint32_t BIAS_SLOT = BUF + UNIT;   // byte offset of A1(1)
-    if (has_bias) {
-      const float* bsrc = g.bias + cn0 + wc * 32;                  // uniform
-      const uint32_t boff = (uint32_t)(((lane >> 5) * 128 + (lane & 31)) * 4);
-      const uint32_t bdst = (uint32_t)(uintptr_t)((lds_void*)smem) + BIAS_SLOT + wave * 256;
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(boff), "s"(bsrc), "s"(bdst) : "memory");
-    }
-    if (have_next) {
-      iu = inext;
-      tile_bases(cbeg + iu, m0, n0, baseA, baseB);
-      prologue(baseA, baseB);
-    }
-    // the bias piece is older than every DMA piece just issued: 14 (nk > 1) or 8 of those may stay in flight
-    if (!have_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    f32x4 bias[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bias[j][q] = has_bias ? *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(
-                                    sm3 + BIAS_SLOT + wave * 256 + (j * 32 + q * 8 + lk * 4) * 4)
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
-    // MFMA results -> v_accvgpr_read: the last MFMA was issued a barrier ago; 16-pass XDL needs 18 wait states
-    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-
-    lds_char* const smw = (lds_char*)smem;
-    const bf16_t* ct = g.C + cm0 * g.ldc + cn0;
-#define PQ_QUADRANT(I, J)                                                                      \
-  do {                                                                                         \
-    pq_park<MODE, I, J>(g, smw, bias[J], lane, wr, wc, cm0, cn0);                              \
-    PQ_BAR_LDS();                                                                              \
-    pq_rows<I, J>(g, sm3, lane, wave, ct + (int64_t)(I) * 128 * g.ldc + (J) * 128);            \
-    PQ_BAR_LDS();                                                                              \
-  } while (0)
-    if (!(g.abl & 2)) {
-      PQ_QUADRANT(0, 0);
-      PQ_QUADRANT(0, 1);
-      PQ_QUADRANT(1, 0);
-      PQ_QUADRANT(1, 1);
-    }
-#undef PQ_QUADRANT
-    if (!have_next) break;
-    // K-tiles 0, 1 must be steady-state K-tiles (n2) for the counted form; the ablation without stores counts none
-    post_store = nk >= 4 && !(g.abl & 3) && !(slowwait);
+  // prologue: K-tile 0 and, of K-tile 1, everything but A1 (issued in R1 of K-tile 0)
+  stage(2, 0);
+  stage(0, 0);
+  stage(3, 0);
+  stage(1, 0);
+  if (nk > 1) {
+    stage(2, 1);
+    stage(0, 1);
+    stage(3, 1);
+    wait_vm<10>();   // B0(0), A0(0) have landed
+  } else {
+    wait_vm<4>();
   }
+  PQ_BAR();
+  read_b(I0{}, integral_constant<int, 2 * UNIT>{}, fbx);
+  if (wr == 1) PQ_BAR();     // group 1 runs one barrier interval behind group 0
+
+  // one K-tile: fbp holds B0(t) on entry and fbq is free; on exit fbq holds B0(t+1)
+  auto ktile = [&](auto bc, auto zc, int t, bf16x8_t (&fbp)[4], bf16x8_t (&fbq)[4]) {
+    typedef decltype(bc) CB;
+    typedef integral_constant<int, 1 - CB::value> NB;
+    typedef decltype(zc) Z;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    // ---- phase 1: quadrant (A0, B0)
+    read_a(CB{}, integral_constant<int, 0>{});
+    if (n1) { stage(1, t + 1); wait_vm<10>(); } else { wait_vm<2>(); }          // retires B1(t), read in R2
+    PQ_BAR();
+    quadrant(I0{}, I0{}, Z{}, fbp);
+    PQ_BAR();
+    // ---- phase 2: quadrant (A0, B1)
+    read_b(CB{}, integral_constant<int, 3 * UNIT>{}, fbq);
+    if (n2) { stage(2, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<8>(); } else { wait_vm<0>(); }   // retires A1(t)
+    PQ_BAR();
+    quadrant(I0{}, I1{}, Z{}, fbq);
+    PQ_BAR();
+    // ---- phase 3: quadrant (A1, B1)
+    read_a(CB{}, integral_constant<int, UNIT>{});
+    if (n2) { stage(0, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<6>(); }   // retires B0(t+1), read in R4
+    PQ_BAR();
+    quadrant(I1{}, I1{}, Z{}, fbq);
+    PQ_BAR();
+    // ---- phase 4: quadrant (A1, B0); B1's registers are free: B0(t+1) goes there
+    if (n1) read_b(NB{}, integral_constant<int, 2 * UNIT>{}, fbq);
+    if (n2) { stage(3, t + 2); wait_vm<10>(); } else if (n1) { wait_vm<4>(); }   // retires A0(t+1), read in R1
+    PQ_BAR();
+    quadrant(I1{}, I0{}, Z{}, fbp);
+    PQ_BAR();
+  };
+  ktile(I0{}, I1{}, 0, fbx, fby);     // first K-tile: the MFMAs overwrite the accumulators (C = 0)
+  int t = 1;
+  for (; t + 1 < nk; t += 2) {
+    ktile(I1{}, I0{}, t, fby, fbx);
+    ktile(I0{}, I0{}, t + 1, fbx, fby);
+  }
+  if (t < nk) ktile(I1{}, I0{}, t, fby, fbx);
+  if (wr == 0) PQ_BAR();     // group 0 catches up: every wave is done with the operand ring, the VM queue is empty
+
+  if (g.abl & 2) return;
+  // ---- output
+  asm volatile("" : "+v"(lane));   // lane-dependent epilogue addresses are derived here, not kept live across the K loop
+  const int li = lane & 31, lk = lane >> 5;
+  lds_char* const smw = (lds_char*)smem;
+  if constexpr (MODE == PQ_DACT8) side_half(1, SI1_OFF);   // lands under the first half's arithmetic
+  f32x4 bias[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bias[j][q] = has_bias ? *reinterpret_cast<lds_cf32x4*>(sm3 + BIAS_OFF + wave * 256 + (j * 32 + q * 8 + lk * 4) * 4)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+  // MFMA results -> v_accvgpr_read: the last MFMA was issued a barrier ago; 16-pass XDL needs 18 wait states
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+
+#define PQ_HALF(I, SI)                                                         \
+  do {                                                                         \
+    pq_block<MODE, I, 0, 0>(g, smw, bias[0], li, lk, wr, wc, SI);              \
+    pq_block<MODE, I, 0, 1>(g, smw, bias[0], li, lk, wr, wc, SI);              \
+    pq_block<MODE, I, 1, 0>(g, smw, bias[1], li, lk, wr, wc, SI);              \
+    pq_block<MODE, I, 1, 1>(g, smw, bias[1], li, lk, wr, wc, SI);              \
+    PQ_BAR_LDS();                                                              \
+    pq_rows_half<MODE, I>(g, sm3, lane, wave, m0, n0);                         \
+    if constexpr (MODE == PQ_ACT8) pq_rows_aux<I>(g, sm3, lane, wave, m0, n0); \
+  } while (0)
+  PQ_HALF(0, SI0_OFF);
+  // second half: its side-in pieces (4 per wave) are older than the first half's 8 output stores of this wave
+  if constexpr (MODE == PQ_DACT8) { if (g.abl & 1) wait_vm<0>(); else wait_vm<8>(); }
+  PQ_BAR_LDS();   // the patches are free again (and every wave's side-in pieces have landed)
+  PQ_HALF(1, SI1_OFF);
+#undef PQ_HALF
 }
 
 }  // namespace
@@ -455,59 +507,65 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
 #ifndef PQ_PART
 #error "compile with -DPQ_PART=0..2 (see build.sh)"
 #endif
-#define PQ_LAUNCHER(NAME, BKS)                                                                        \
-  void NAME(int mode, dim3 grid, hipStream_t stream, const void* args) {                              \
-    const PQArgs g = *reinterpret_cast<const PQArgs*>(args);                                          \
-    hipLaunchKernelGGL((gemm_bf16_pq_kernel<BKS, PQ_PLAIN>), grid, dim3(NWV * 64), 0, stream, g);     \
-  }
+#define PQ_LAUNCH(BKS, MODE) hipLaunchKernelGGL((gemm_bf16_pq_kernel<BKS, MODE>), grid, dim3(NWV * 64), 0, stream, g)
 #if PQ_PART == 0
-PQ_LAUNCHER(segclip_pq_launch_f, false)
+void segclip_pq_launch_f(int mode, dim3 grid, hipStream_t stream, const void* args) {   // forward: plain / QuickGELU + saved derivative
+  const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
+  if (mode == PQ_ACT8) PQ_LAUNCH(false, PQ_ACT8);
+  else PQ_LAUNCH(false, PQ_PLAIN);
+}
 #elif PQ_PART == 1
-PQ_LAUNCHER(segclip_pq_launch_k, true)
+void segclip_pq_launch_k(int mode, dim3 grid, hipStream_t stream, const void* args) {   // data gradient: plain / x saved derivative
+  const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
+  if (mode == PQ_DACT8) PQ_LAUNCH(true, PQ_DACT8);
+  else PQ_LAUNCH(true, PQ_PLAIN);
+}
 #endif
 
 #if PQ_PART == 2
 void segclip_pq_launch_f(int, dim3, hipStream_t, const void*);
 void segclip_pq_launch_k(int, dim3, hipStream_t, const void*);
 
-// Launch the persistent kernel when the problem meets its preconditions (see the top of the file); false = not taken.
+// Launch this kernel when the problem meets its preconditions (see the top of the file); false = not taken.
 bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t nb, hipStream_t stream) {
   // SEGCLIP_GEMM_PQ: 1 (default) on, 0 off, 2 = consult SEGCLIP_GEMM_PQ_NOW (0/1) at every call (A/B tests in one process)
-  static const int mode = [] { const char* e = getenv("SEGCLIP_GEMM_PQ"); return e ? atoi(e) : 1; }();
-  if (mode == 0) return false;
-  if (mode == 2) { const char* e = getenv("SEGCLIP_GEMM_PQ_NOW"); if (e && atoi(e) == 0) return false; }
+  static const int mode_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ"); return e ? atoi(e) : 1; }();
+  if (mode_env == 0) return false;
+  if (mode_env == 2) { const char* e = getenv("SEGCLIP_GEMM_PQ_NOW"); if (e && atoi(e) == 0) return false; }
   const Args& a = *reinterpret_cast<const Args*>(args_);
   const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
   if (a_ks || splits != 1 || nb != 1) return false;
   if (d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16 || d->c_dtype != SEGCLIP_BF16) return false;
   if (d->M % BT != 0 || d->N % BT != 0 || d->K % BK != 0 || d->K < BK) return false;
-  if (d->alpha != 1.0f || a.colsum_part != nullptr) return false;
-  if (d->residual != nullptr || d->aux != nullptr || d->act != SEGCLIP_ACT_NONE || d->mul_dact) return false;   // PQ_PLAIN only so far
+  if (d->alpha != 1.0f || d->residual != nullptr) return false;
+  int mode = PQ_PLAIN;
+  if (d->mul_dact) {            // x act'(u), saved as one byte; optional fused column sums
+    if (!(d->aux && d->aux_kind == 2 && d->act == SEGCLIP_ACT_QUICK_GELU && !d->bias && b_ks && d->ldaux % 16 == 0)) return false;
+    mode = PQ_DACT8;
+  } else if (d->act != SEGCLIP_ACT_NONE) {   // QuickGELU + saved derivative as one byte
+    if (!(d->aux && d->aux_kind == 2 && d->act == SEGCLIP_ACT_QUICK_GELU && !b_ks && d->ldaux % 16 == 0)) return false;
+    mode = PQ_ACT8;
+  } else if (d->aux) {
+    return false;
+  }
+  if (a.colsum_part != nullptr && mode != PQ_DACT8) return false;
   auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (!al(d->A) || !al(d->B) || !al(d->C) || !al(d->bias) || d->ldc % 8 != 0) return false;
+  if (!al(d->A) || !al(d->B) || !al(d->C) || !al(d->bias) || !al(d->aux) || d->ldc % 8 != 0) return false;
   const int64_t lda = d->sam, ldb = b_ks ? d->sbk : d->sbn;
   if (lda % 8 != 0 || ldb % 8 != 0) return false;
-  // 32-bit per-lane offsets: 256 rows (64 k-rows) of an operand and 256 rows of the output stay below 2 GiB
+  // 32-bit per-lane offsets: 256 rows (64 k-rows) of an operand and 256 rows of an output stay below 2 GiB
   if (256 * lda * 2 >= (int64_t)1 << 31 || (b_ks ? 64 : 256) * ldb * 2 >= (int64_t)1 << 31) return false;
-  if (256 * d->ldc * 2 >= (int64_t)1 << 31) return false;
+  if (256 * d->ldc * 2 >= (int64_t)1 << 31 || 256 * d->ldaux >= (int64_t)1 << 31) return false;
   PQArgs g;
   g.A = reinterpret_cast<const bf16_t*>(d->A); g.B = reinterpret_cast<const bf16_t*>(d->B);
   g.C = reinterpret_cast<bf16_t*>(d->C); g.bias = d->bias;
-  g.side = nullptr; g.aux = nullptr; g.colsum_part = nullptr;
-  g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = 0; g.ldaux = 0;
+  g.side = mode == PQ_DACT8 ? d->aux : nullptr;
+  g.aux = mode == PQ_ACT8 ? reinterpret_cast<uint8_t*>(d->aux) : nullptr;
+  g.colsum_part = a.colsum_part;
+  g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = d->ldaux; g.ldaux = d->ldaux;
   g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
-  // one workgroup per CU (160 KiB of LDS); SEGCLIP_PQ_PERSIST=0: one tile per workgroup (the same kernel, no tile loop taken)
-  static const int persist0 = [] { const char* e = getenv("SEGCLIP_PQ_PERSIST"); return e ? atoi(e) : 1; }();
-  int persist = persist0;
-  if (mode == 2) { const char* e = getenv("SEGCLIP_PQ_PERSIST_NOW"); if (e) persist = atoi(e); }
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  { const char* e = mode == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
-  const int grid = persist && g.ntiles > ncu ? ncu : g.ntiles;
-  (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(PQ_PLAIN, dim3((unsigned)grid), stream, &g);
+  { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
+  (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3((unsigned)g.ntiles), stream, &g);
   return true;
 }
 #endif  // PQ_PART == 2

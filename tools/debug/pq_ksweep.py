@@ -14,7 +14,7 @@ print(f"M {M} N {N}: {(M // 256) * (N // 256)} tiles = {(M // 256) * (N // 256) 
 for K in (64, 128, 256, 512, 768, 1536, 3072):
     x = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF); b = torch.randn(N, device="cuda")
     row = [f"K {K:5d}"]
-    for tag, pq, ps, abl in (("p8", 0, 0, 0), ("pq1", 1, 0, 0), ("pqP", 1, 1, 0), ("pqP-slowwait", 1, 1, 4), ("pqP-nostore", 1, 1, 1), ("pqP-noepi", 1, 1, 2)):
+    for tag, pq, ps, abl in (("p8", 0, 0, 0), ("pq", 1, 0, 0), ("pq-nostore", 1, 0, 1), ("pq-noepi", 1, 0, 2)):
         mode(pq, ps); os.environ["SEGCLIP_PQ_ABL"] = str(abl)
         ops.p_linear(x, w, b); ops.p_linear(x, w, b)
         ts = sorted(timeit(lambda: ops.p_linear(x, w, b)) for _ in range(3))
