@@ -58,6 +58,8 @@ def parse():
                     help="e4m3 MFMA for QK^T / PV in the self-attention forward.  auto = off: at head_dim 64 the non-scaled e4m3 "
                          "MFMA runs at the bf16 rate and the quantisation passes make the step slower (1281 vs 1308 pairs/s on "
                          "configs[4], profiles/r03_bench_configs.json); `on` keeps the configs[4] switch reachable")
+    ap.add_argument("--resid", default="auto", choices=["auto", "bf16", "fp32"],
+                    help="residual stream between the blocks of a tower in bf16 mode (config.bf16_resid); auto = the package default")
     ap.add_argument("--text-after-blocks", type=int, default=-1, help="config.text_after_blocks override (launch order of the towers)")
     ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format (auto = fp32, what the reference DDP exchanges; bf16 is an opt-in)")
     ap.add_argument("--rccl-channels", type=int, default=0,
@@ -192,7 +194,7 @@ def respawn(a):
 def child_argv(a, steps, warmup):
     """bench.py command line of the same per-GPU workload on ONE GPU, without the roofline / CPU-baseline legs."""
     argv = [os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch", str(a.batch),
-            "--spec", a.spec, "--dtype", a.dtype, "--attn-fp8", a.attn_fp8, "--no-roofline", "--no-cpu-baseline"]
+            "--spec", a.spec, "--dtype", a.dtype, "--attn-fp8", a.attn_fp8, "--resid", a.resid, "--no-roofline", "--no-cpu-baseline"]
     if a.full_loss:
         argv.append("--full-loss")
     return argv
@@ -267,7 +269,7 @@ def roofline_block(a, step, pairs_per_gpu, world, work, collective_free=True):
         if extra in cl:
             classes[extra] = {"time_per_step_ms": cl[extra]["time_per_step_ms"], "launches_per_step": cl[extra]["launches_per_step"]}
     tr = m["traffic"]
-    return {"bound": "mfma", "kernel": "gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback), all launches of a step",
+    return {"bound": "mfma", "kernel": "gemm_bf16_pq_kernel / gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback), all launches of a step",
             "achieved": g["achieved"], "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": g["frac"],
             "avg_launch_us": g["avg_launch_us"], "launches_per_step": g["launches_per_step"],
             "time_per_step_ms": g["time_per_step_ms"],
@@ -346,6 +348,8 @@ def main():
     segclip_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     attn_fp8 = a.dtype == "bf16" and a.attn_fp8 == "on"
     segclip_amd.config.attn_fp8 = attn_fp8
+    if a.resid != "auto":
+        segclip_amd.config.bf16_resid = a.resid == "bf16"
     if a.text_after_blocks >= 0:
         segclip_amd.config.text_after_blocks = a.text_after_blocks
     if os.environ.get("SEGCLIP_OVERLAP_WGRAD", "0") == "1":   # experiment switch: weight gradients on a second stream
@@ -434,6 +438,8 @@ def main():
                                             ("bf16" if net._flat and net._use_bf16(net._flat[0]) else "fp32") +
                                             f", zero-copy grads {net.stats['zero_copy']}/{net.stats['zero_copy'] + net.stats['copies']}"
                                             f", backend {a.backend}, RCCL channels {a.rccl_channels or 'default'}"),
+                          "residual_stream": ("bf16 between the blocks of a tower, fp32 at the tower boundaries"
+                                              if (a.dtype == "bf16" and segclip_amd.config.bf16_resid) else "fp32"),
                           "cross_mode": segclip_amd.config.cross_mode, "loss": round(loss_val, 5)},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

@@ -362,6 +362,35 @@ typedef struct segclip_adamw_tensor {
   int32_t group; /* index into groups[] */
 } segclip_adamw_tensor;
 
+/* Grouped 64-channel linear layers on channel-last rows = nn.Conv1d(D, D, kernel_size 1, groups = D/64, bias=False), the
+ * k_conv / v_conv of the learnable-center stage (reference modules/module_seg_vit.py:266,269 applied at :299,302):
+ *   out_o(m, g*64 + n) = sum_i sum_k in_i(m, g*64 + k) * w[i*n_out + o][g*64 + n][k],   bf16 in / out, fp32 accumulation.
+ * (n_in, n_out) = (1, 1), (1, 2): one or two convolutions of the same input in one pass; (2, 1): sum of two - their data
+ * gradient when w holds the per-group TRANSPOSED weights.  in/out/w and the pitches are HOST arrays; w[.]: (groups*64, 64)
+ * bf16 row-major; all pointers 16-byte aligned, pitches multiples of 8 elements. */
+int segclip_group_linear64(const void* const* in, const int64_t* ld_in, int n_in, void* const* out, const int64_t* ld_out,
+                           int n_out, const void* const* w, int64_t M, int groups, void* stream);
+
+/* ---- pooled-feature head and contrastive loss (csrc/head.hip) ------------------------------------------------------
+ * out[b][d] = max_t x[b][t][d], idx = first arg-max token (torch.max(x, dim=1), reference modules/module_seg_vit.py:441);
+ * backward: dx[b][t][d] = dout[b][d] if t == idx[b][d] else 0, written as fp32 (dx, nullable) and / or bf16 (dx_bf16). */
+int segclip_max_tokens_fwd(const float* x, float* out, int32_t* idx, int64_t B, int64_t T, int64_t D, void* stream);
+int segclip_max_tokens_bwd(const float* dout, const int32_t* idx, float* dx, void* dx_bf16, int64_t B, int64_t T, int64_t D,
+                           void* stream);
+/* both[b][0] = v[b] / |v[b]|, both[b][1] = t[b] / |t[b]| (B, 2, C) - the stacked message of the embedding all-gather
+ * (reference modules/modeling.py:341-345,352-354); norms (2B).  Backward: dv, dt from dboth (+ dboth2, nullable). */
+int segclip_l2norm_pair_fwd(const float* v, const float* t, float* both, float* norms, int64_t B, int64_t C, void* stream);
+int segclip_l2norm_pair_bwd(const float* dboth, const float* dboth2, const float* both, const float* norms, float* dv,
+                            float* dt, int64_t B, int64_t C, void* stream);
+/* cos (2, B, N) raw cosines ([0] = t v_all^T, [1] = v t_all^T); logits = min(exp(*logit_scale), 100) * cos; row r of either
+ * matrix has label r + label_offset; *loss = mean of the 2B row losses = (CE(t2v) + CE(v2t)) / 2 (reference
+ * modules/modeling.py:204-209,346-362).  Backward: dcos = (*g / 2B) * scale * (softmax - onehot); *dlogit_scale (nullable)
+ * = d loss / d logit_scale through the clamp.  lse, loss_rows, ds_rows: (2B) workspaces / saved statistics. */
+int segclip_clip_ce_fwd(const float* cos, const float* logit_scale, float* lse, float* loss_rows, float* loss, int64_t B,
+                        int64_t N, int64_t label_offset, void* stream);
+int segclip_clip_ce_bwd(const float* cos, const float* lse, const float* logit_scale, const float* g, float* dcos,
+                        float* ds_rows, float* dlogit_scale, int64_t B, int64_t N, int64_t label_offset, void* stream);
+
 /* dst[i][:] = bf16(src[i][:]) for `count` fp32 tensors in ceil(count/32) launches (the compute-dtype copies of the
  * GEMM weights, refreshed once per forward instead of one cast launch per weight).  src/dst/n are HOST arrays. */
 int segclip_multi_cast_bf16(const float* const* src, void* const* dst, const int64_t* n, int64_t count, void* stream);

@@ -54,7 +54,7 @@ def mha_core(q, k, v, n_head, causal=False, key_mask=None):
     vh = v.reshape(B, Tk, n_head, hd).permute(0, 2, 1, 3)
     s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
     if causal:
-        mask = torch.full((Tq, Tk), float("-inf"), dtype=s.dtype).triu_(1)
+        mask = torch.full((Tq, Tk), float("-inf"), dtype=s.dtype, device=s.device).triu_(1)
         s = s + mask
     if key_mask is not None:   # (B, Tk) 1 = attend: additive (1 - mask) * -1e6 (modules/module_mae.py:216-219)
         s = s + ((1.0 - key_mask.to(s.dtype)) * -1000000.0)[:, None, None, :]
@@ -157,7 +157,7 @@ def random_masking(x, noise, mask_ratio):
     ids_restore = torch.argsort(ids_shuffle, dim=1)
     ids_keep = ids_shuffle[:, :len_keep]
     x_masked = torch.gather(x, 1, ids_keep.unsqueeze(-1).repeat(1, 1, D))
-    mask = torch.ones(N, L, dtype=x.dtype)
+    mask = torch.ones(N, L, dtype=x.dtype, device=x.device)
     mask[:, :len_keep] = 0
     mask = torch.gather(mask, 1, ids_restore)
     return x_masked, mask, ids_restore, ids_keep
@@ -290,7 +290,7 @@ def random_masking_text(x, noise, mask_ratio, sep_pos):
     ids_restore = torch.argsort(ids_shuffle, dim=1, stable=True)
     ids_keep = ids_shuffle[:, :len_keep]
     x_masked = torch.gather(x, 1, ids_keep.unsqueeze(-1).repeat(1, 1, D))
-    mask = torch.ones(N, L, dtype=x.dtype)
+    mask = torch.ones(N, L, dtype=x.dtype, device=x.device)
     mask[:, :len_keep] = 0
     mask = torch.gather(mask, 1, ids_restore)
     return x_masked, mask, ids_restore, ids_keep
@@ -369,7 +369,7 @@ def loose_similarity(text_feat, img_feat, logit_scale, gather=None):
 def contrastive_loss(t2v, v2t, rank=0):
     """modules/modeling.py:204-210."""
     B = t2v.shape[0]
-    labels = torch.arange(B, dtype=torch.long) + B * rank
+    labels = torch.arange(B, dtype=torch.long, device=t2v.device) + B * rank
     return (F.cross_entropy(t2v, labels) + F.cross_entropy(v2t, labels)) / 2.0
 
 

@@ -108,6 +108,13 @@ SIGNATURES = {
     "segclip_mask_sort": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
     "segclip_interp_bicubic": (C.c_int, [vp, vp, i64, i64, i64, i64, vp]),
     "segclip_multi_cast_bf16": (C.c_int, [vp, vp, vp, i64, vp]),
+    "segclip_max_tokens_fwd": (C.c_int, [vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_max_tokens_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_l2norm_pair_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, vp]),
+    "segclip_l2norm_pair_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, vp]),
+    "segclip_clip_ce_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_clip_ce_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_group_linear64": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, i64, C.c_int, vp]),
     "segclip_grad_sqnorm_ws_bytes": (C.c_size_t, [vp, i64]),
     "segclip_grad_sqnorm": (C.c_int, [vp, vp, i64, vp, vp, f32, vp]),
     "segclip_adamw_step": (C.c_int, [vp, i64, vp, i64, vp, vp, C.c_int, vp]),
@@ -139,10 +146,14 @@ def load():
     return lib
 
 
+class Unsupported(RuntimeError):
+    """SEGCLIP_ERR_UNSUPPORTED (-2): the library has no kernel for this combination; nothing was launched."""
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().segclip_last_error_string().decode(errors="replace")
-        raise RuntimeError(f"segclip_hip {what} failed (rc={rc}): {msg}")
+        raise (Unsupported if rc == -2 else RuntimeError)(f"segclip_hip {what} failed (rc={rc}): {msg}")
 
 
 def stream():

@@ -25,6 +25,12 @@ attn_fp8      : bf16 mode only: the self-attention FORWARD of the residual block
 fuse_res_stack: consecutive residual blocks of a tower run as ONE autograd node (ops.ResStackFn) instead of one per block
 bf16_resgrad  : bf16 mode, inside ResStackFn: the residual-stream gradient travels between the LayerNorm backwards as
                 one bf16 tensor (10 instead of 16 bytes per element); False keeps it fp32
+bf16_resid    : bf16 mode, inside ResStackFn: the residual STREAM itself is bf16 between the blocks of a stack (fp32 at
+                the tower boundaries and in every LayerNorm statistic): the out_proj / c_proj epilogues and every
+                LayerNorm pass move 2 bytes less per element.  Implies the bf16 gradient chain
+aux_u8        : bf16 mode: the towers keep QuickGELU'(u) for the backward as ONE BYTE per element where the MLP GEMMs run
+                on full 256 x 256 tiles (q = rint((act' + 0.125) * 204), absolute error <= 0.0025 - about bf16's relative
+                error at the typical magnitude, unbounded RELATIVE error near act' = 0); False keeps it as bf16
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -37,7 +43,9 @@ import types
 import torch
 
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
-                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, text_after_blocks=4)
+                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False,
+                 aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
+                 text_after_blocks=4)
 _tls = threading.local()
 
 

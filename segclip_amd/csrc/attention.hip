@@ -51,6 +51,16 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* t, int rbase, int cbase,
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return __builtin_bit_cast(bf16x8_t, r);
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+// the same fragment from precomputed lane offsets (rows r0 .. r0+3 and r0+8 .. r0+11 of a 16-row group)
+__device__ __forceinline__ bf16x8_t frag_tr_at(const char* t, int off_lo, int off_hi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t + off_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t + off_hi));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
   u32x4 r;
 #pragma unroll
@@ -95,11 +105,13 @@ struct FwdArgs {
   float scale; int causal;
   const int* klen;  // nullable: valid keys per sample
   int staged;       // bf16 forward: output rows through LDS (SEGCLIP_ATTN_FWD_STAGED)
+  int lean;         // bf16 forward: the lean softmax step on unmasked key tiles (SEGCLIP_ATTN_FWD_LEAN, default on)
 };
 
 constexpr int KCHUNK = 256;
 
-__global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
+// 4 waves per SIMD (two 7-wave workgroups per CU): at most 128 VGPRs
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_bf16_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KCHUNK * ROWB];
   char* Kt = smem;
   char* Vt = smem + KCHUNK * ROWB;
@@ -128,6 +140,19 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m = -INFINITY, l = 0.f;
+  // lane-constant LDS offsets of the K fragments (k chunk kc) and of the four 8-row groups of the transposed V fragments
+  // (V: rows r0 and r0 + 8 of a 32-key tile per 32-column half; rows + 16 / + 24 are the same offsets + 2048 bytes, since
+  // the swizzle only looks at bits 1-3 of the row)
+  int koff[4], voff[2][2];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) koff[kc] = swz(li, kc * 16 + 8 * lh);
+  {
+    const int g4 = lane >> 4, q = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) voff[dt][j] = swz(4 * (g4 >> 1) + (q >> 2) + 8 * j, dt * 32 + 16 * (g4 & 1) + 4 * (q & 3));
+  }
 
   for (int c0 = 0; c0 < a.Tk; c0 += KCHUNK) {
     const int nvalid = a.Tk - c0 < KCHUNK ? a.Tk - c0 : KCHUNK;
@@ -137,8 +162,61 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
     stage_rows(Vt, Vp, a.v_st, c0, nvalid, npad, a.hd, tid, blockDim.x);
     __syncthreads();
     if (!wave_active) continue;
-    for (int kt = 0; kt < npad; kt += 32) {
+    // Unmasked key tiles (all but the last one of a vision sequence) take a leaner softmax step (round 4; PMC round 3: 27 VALU
+    // instructions per MFMA, MFMA busy 14.7 %): the row maximum is taken over the RAW scores (the scale is positive), so that
+    // scale and shift are one fused multiply-add per score (packed: two scores per instruction); the exponentials are
+    // summed pairwise and packed to bf16 as they are produced; the rescale of the 32 output accumulators is skipped when no
+    // row's maximum moved (wave-uniform test); and the lane-dependent LDS offsets are computed once per kernel
+    // (swz(kt + r, c) = kt * ROWB + swz(r, c) for kt a multiple of 16): ~60 VALU instructions per tile instead of ~130.
+    int kt = 0;
+    while (kt < npad) {
       if (a.causal && c0 + kt > q0 + 31) break;
+      const bool edge = c0 + kt + 32 > kvalid || (a.causal && c0 + kt + 31 > q0);
+      if (!edge && a.lean) {
+        const char* kb = Kt + kt * ROWB;
+        const char* vb = Vt + kt * ROWB;
+        f32x16 s0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+          s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(kb + koff[kc]), qf[kc], s0, 0, 0, 0);
+        float mx = fmaxf(s0[0], s0[1]);
+#pragma unroll
+        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx * sc2);            // finite: an unmasked tile has 32 real scores per row
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);   // m = -inf (first step) -> 0
+        const v2f sc2v = v2f{sc2, sc2}, nmv = v2f{-mn, -mn};
+        v2f rs2 = v2f{0.f, 0.f};
+        u32x4 pk[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const v2f e0 = v2f{s0[2 * j], s0[2 * j + 1]} * sc2v + nmv;
+          const v2f x0 = v2f{__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};
+          rs2 += x0;
+          pk[j >> 2][j & 3] = pack2bf(x0[0], x0[1]);
+        }
+        float rs = rs2[0] + rs2[1];
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+          const v2f av = v2f{alpha, alpha};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const v2f a0 = v2f{o[0][2 * j], o[0][2 * j + 1]} * av, a1 = v2f{o[1][2 * j], o[1][2 * j + 1]} * av;
+            o[0][2 * j] = a0[0]; o[0][2 * j + 1] = a0[1]; o[1][2 * j] = a1[0]; o[1][2 * j + 1] = a1[1];
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(vb, voff[dt][0], voff[dt][1]), __builtin_bit_cast(bf16x8_t, pk[0]), o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(vb + 16 * ROWB, voff[dt][0], voff[dt][1]), __builtin_bit_cast(bf16x8_t, pk[1]), o[dt], 0, 0, 0);
+        }
+        kt += 32;
+        continue;
+      }
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -147,7 +225,6 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kt, kc, lane), qf[kc], s, 0, 0, 0);
       // softmax in the log2 domain (one fma + v_exp_f32 per element); the key / causal masks are only evaluated on
       // tiles that contain masked elements (wave-uniform test)
-      const bool edge = c0 + kt + 32 > kvalid || (a.causal && c0 + kt + 31 > q0);
       float p[16];
       float mx = -INFINITY;
       if (edge) {
@@ -180,6 +257,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(FwdArgs a) {
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt, dt * 32, lane), pb0, o[dt], 0, 0, 0);
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt + 16, dt * 32, lane), pb1, o[dt], 0, 0, 0);
       }
+      kt += 32;
     }
   }
   // Output.  The accumulators hold transposed tiles (lane = query row, registers = 4 consecutive columns): stored from
@@ -615,6 +693,8 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     // LDS-staged output rows: 117 -> 112 us at T = 196 (B = 256, H = 12), 27.8 -> 29.3 us at T = 77: on for the long sequences
     static const int fwd_staged = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_STAGED"); return e ? atoi(e) : -1; }();
     a.staged = fwd_staged >= 0 ? fwd_staged : (d->Tq > 128 ? 1 : 0);
+    static const int fwd_lean = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_LEAN"); return e ? atoi(e) : 1; }();
+    a.lean = fwd_lean;
     SEGCLIP_REQUIRE(!(d->klen && (d->flags & SEGCLIP_ATTN_FP8)), "attn_fwd: klen is not supported by the fp8 kernel");
     const int tiles = (int)cdiv(d->Tq, 32);
     const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
@@ -704,25 +784,28 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     static const int use_sp = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_SP"); return e ? atoi(e) : 1; }();
     if (use_sp && d->Tq == d->Tk) {
       const size_t lds_sp = bwd_sp_lds_bytes(tiles * 32);
-      static bool sp_attr_set = false;
-      if (!sp_attr_set) {
+      // per DEVICE (function attributes and the CU count belong to the device the launch goes to, not to the process)
+      int dev = 0;
+      SEGCLIP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "attn_bwd: cannot query the current device");
+      static bool sp_attr_set[64] = {};
+      static int ncu_dev[64] = {};
+      if (!sp_attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_bf16_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_sp_lds_bytes(TMAX));
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_bf16_kernel<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_sp_lds_bytes(TMAX));
         SEGCLIP_REQUIRE(e == hipSuccess && e2 == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        sp_attr_set = true;
+        sp_attr_set[dev] = true;
       }
       // persistent grid: as many workgroups as the chip holds at once (LDS / registers: 1 per CU at T = 197, more for the
       // short text sequences); SEGCLIP_ATTN_BWD_GRID overrides the number per CU (0 = one workgroup per item)
       const bool masked = d->causal || d->klen;
-      static int ncu = 0;
-      if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            ncu <= 0)
-          ncu = 256;
+      if (ncu_dev[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        ncu_dev[dev] = n;
       }
+      const int ncu = ncu_dev[dev];
       static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_GRID"); return e ? atoi(e) : -1; }();
       int per_cu = 0;
       hipError_t eo = masked ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_sp_bf16_kernel<true>, tiles * 64, lds_sp)

@@ -32,7 +32,7 @@ for part in $parts; do
     pids+=($!)
   fi
 done
-for part in 0 1 2; do   # persistent 256x256 kernel (gemm_bf16_pq.hip): forward layout, data-gradient layout, dispatcher
+for part in 0 1 2 3; do   # AGPR-accumulator 256x256 kernel (gemm_bf16_pq.hip): forward layout, data-gradient layout, dispatcher, weight-gradient layout
   f=gemm_bf16_pq.hip; o=build/gemm_bf16_pq_part$part.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
     throttle; $HIPCC $FLAGS -DPQ_PART=$part -c $f -o $o &
@@ -47,7 +47,7 @@ for part in 0 1 2 3 4; do
     pids+=($!)
   fi
 done
-for f in gemm_f32.hip layernorm.hip attention.hip misc.hip optim.hip capi.cpp; do
+for f in gemm_f32.hip layernorm.hip attention.hip misc.hip group_linear.hip head.hip optim.hip capi.cpp; do
   [ -f "$f" ] || continue
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then

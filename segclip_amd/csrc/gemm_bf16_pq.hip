@@ -49,15 +49,17 @@ constexpr int SI1_OFF = 98304;                // side-in of the second half (PQ_
 constexpr int SI0_OFF = EXTRA;                // side-in of the first half, fetched during the K loop
 constexpr int BIAS_OFF = EXTRA;               // bias: wave * 256 B (modes with a bias have no side-in)
 
-enum { PQ_PLAIN = 0, PQ_RES = 1, PQ_ACT8 = 2, PQ_DACT8 = 3 };
+enum { PQ_PLAIN = 0, PQ_RES = 1, PQ_ACT8 = 2, PQ_DACT8 = 3, PQ_SLAB = 4, PQ_RES32 = 5 };
 
 struct PQArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C; const float* bias;
-  const void* side;      // PQ_RES: bf16 residual (ld = lds); PQ_DACT8: uint8 saved derivative (ld = lds)
+  const void* side;      // PQ_RES: bf16 / PQ_RES32: fp32 residual (ld = lds); PQ_DACT8: uint8 saved derivative (ld = lds)
   uint8_t* aux;          // PQ_ACT8: uint8 saved derivative out (ld = ldaux)
   float* colsum_part;    // PQ_DACT8, optional: [M/64][N] partial column sums of the stored output
   int64_t lda, ldb, ldc, lds, ldaux;
   int N, K, nbx, ntiles;
+  float* Cf;             // PQ_SLAB / PQ_RES32: fp32 output (split-K: slab of K range s at Cf + s * slab_stride), row pitch ldc
+  int64_t kper, slab_stride;   // PQ_SLAB: K elements per split (a multiple of 64)
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
@@ -214,6 +216,9 @@ __device__ __forceinline__ void pq_block(const PQArgs& g, lds_char* sm, const f3
         const float qf = (float)((q >> (8 * k)) & 0xffu);   // v_cvt_f32_ubyteN
         w[k] = v[gq * 4 + k] * (qf * (1.0f / AUX8_SCALE) - AUX8_OFF);
       }
+    } else if constexpr (MODE == PQ_RES) {   // bias and residual join in the row pass
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = v[gq * 4 + k];
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) w[k] = v[gq * 4 + k] + bias[gq][k];
@@ -286,6 +291,48 @@ __device__ __forceinline__ void pq_rows_half(const PQArgs& g, lds_cchar* sm, int
     }
   }
 }
+// PQ_RES: the bf16 residual rows of the wave's row-pass patch (the store mapping of pq_rows_half), 8 x 16 bytes per lane
+// and half, fetched with ordinary loads long before they are used (the registers of the operand fragments are free)
+template <int I>
+__device__ __forceinline__ void pq_res_issue(const PQArgs& g, int lane, int wave, int64_t m0, int64_t n0, u32x4 (&res)[8]) {
+  const int J = wave >> 2, rh = (wave >> 1) & 1, ch = wave & 1;
+  const int rs = lane >> 3, c = ch * 8 + (lane & 7);
+  const int64_t ldsb = g.lds * 2;
+  const char* rq = reinterpret_cast<const char*>(g.side) + ((m0 + I * 128 + rh * 64 + rs) * g.lds + n0 + J * 128 + c * 8) * 2;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) res[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rq + (int64_t)it * 8 * ldsb));
+}
+// row pass of one half with the residual (and the bias) added: out = bf16(parked bf16(acc) + bias + residual)
+template <int I>
+__device__ __forceinline__ void pq_rows_half_res(const PQArgs& g, lds_cchar* sm, int lane, int wave, int64_t m0, int64_t n0,
+                                                 const u32x4 (&res)[8], const float (&bv)[8]) {
+  const int J = wave >> 2, rh = (wave >> 1) & 1, ch = wave & 1;
+  const int rs = lane >> 3, cl = lane & 7;
+  const int c = ch * 8 + cl;
+  const uint32_t rd = H_OFF + J * 32768 + (uint32_t)(rh * 64 + rs) * 256 + ((uint32_t)(c ^ rs) << 4);
+  const int64_t ldcb = g.ldc * 2;
+  const char* cq = reinterpret_cast<const char*>(g.C + (m0 + I * 128 + rh * 64) * g.ldc + n0 + J * 128);   // uniform
+  const uint32_t go = (uint32_t)(rs * ldcb + c * 16);
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    u32x4 d[4];
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) d[i4] = *reinterpret_cast<lds_cu32x4*>(sm + rd + (h2 * 4 + i4) * 2048);
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int it = h2 * 4 + i4;
+      if (it & 1) d[i4] = u32x4{d[i4][2], d[i4][3], d[i4][0], d[i4][1]};
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(d[i4][k] << 16) + __uint_as_float(res[it][k] << 16) + bv[2 * k];
+        const float hi = __uint_as_float(d[i4][k] & 0xffff0000u) + __uint_as_float(res[it][k] & 0xffff0000u) + bv[2 * k + 1];
+        o[k] = pack2bf(lo, hi);
+      }
+      if (!(g.abl & 1)) store16_nt(cq + (int64_t)it * 8 * ldcb, go, o);
+    }
+  }
+}
 // uint8 saved-derivative patches of one half -> global: wave w moves rows (w&3)*32 .. +31 of quadrant J = w>>2
 template <int I>
 __device__ __forceinline__ void pq_rows_aux(const PQArgs& g, lds_cchar* sm, int lane, int wave, int64_t m0, int64_t n0) {
@@ -304,7 +351,67 @@ __device__ __forceinline__ void pq_rows_aux(const PQArgs& g, lds_cchar* sm, int 
   }
 }
 
-template <bool B_KS, int MODE>
+// ---- fp32 output (PQ_SLAB: weight gradients, raw split-K partial tiles).  fp32 patch of a quadrant: [128 rows][512 B];
+// 16-byte chunk c (4 columns) of row R is stored at chunk c ^ (R & 15): the 16 lanes a ds_write_b128 services together
+// (16 consecutive rows, one column group) hit the 16 different 16-byte slots of a 256-byte bank window, and so do the 16
+// lanes of a ds_read_b128 of the row pass (16 consecutive chunks of one row).  Two quadrants = the whole 128-KiB ring.
+template <int I, int J, int RI>
+__device__ __forceinline__ void pq_block_f32(lds_char* sm, int li, int lk, int wr, int wc) {
+  float v[16];
+  acc_read8<((I * 2 + RI) * 2 + J) * 16>(v);
+  acc_read8<((I * 2 + RI) * 2 + J) * 16 + 8>(v + 8);
+  const uint32_t row = (uint32_t)(wr * 64 + RI * 32 + li);
+  const uint32_t base = J * 65536 + row * 512;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const uint32_t chunk = (uint32_t)wc * 8 + 2 * gq + lk;
+    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(sm + base + ((chunk ^ (row & 15)) << 4)) =
+        f32x4{v[gq * 4], v[gq * 4 + 1], v[gq * 4 + 2], v[gq * 4 + 3]};
+  }
+}
+__device__ __forceinline__ void store16(const void* base_uniform, uint32_t off, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base_uniform) : "memory");
+}
+// row pass: wave w moves rows (w&3)*32 .. +31 of quadrant J = w>>2, two whole 512-byte rows per instruction (16 instructions;
+// Q = 0 / 1: the first / second 8 of them).  RES: out = (parked acc + bias) + residual, all fp32 - the arithmetic and the
+// rounding of the 8-phase kernel's fp32-residual epilogue
+template <int I, int Q, bool RES>
+__device__ __forceinline__ void pq_rows_q_f32(const PQArgs& g, float* out, lds_cchar* sm, int lane, int wave, int64_t m0,
+                                              int64_t n0, const f32x4 (&res)[8], const f32x4& bias4) {
+  const int J = wave >> 2, rb = (wave & 3) * 32;
+  const int r2 = lane >> 5, c = lane & 31;
+  const uint32_t rd = J * 65536 + (uint32_t)(rb + r2) * 512;
+  const uint32_t cx = (uint32_t)(c ^ r2);                      // (R & 15) = ((2 it) & 15) | r2 for R = rb + 2 it + r2
+  const int64_t ldcb = g.ldc * 4;
+  const char* cq = reinterpret_cast<const char*>(out + (m0 + I * 128 + rb) * g.ldc + n0 + J * 128);   // uniform
+  const uint32_t go = (uint32_t)(r2 * ldcb + c * 16);
+#pragma unroll
+  for (int h4 = 0; h4 < 2; ++h4) {
+    f32x4 d[4];
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int it = Q * 8 + h4 * 4 + i4;
+      d[i4] = *reinterpret_cast<lds_cf32x4*>(sm + rd + it * 1024 + ((cx ^ (uint32_t)((2 * it) & 15)) << 4));
+    }
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int it = Q * 8 + h4 * 4 + i4;
+      if constexpr (RES) d[i4] = (d[i4] + bias4) + res[h4 * 4 + i4];
+      if (!(g.abl & 1)) store16(cq + (int64_t)it * 2 * ldcb, go, __builtin_bit_cast(u32x4, d[i4]));
+    }
+  }
+}
+// PQ_RES32: the fp32 residual rows of instructions Q*8 .. +7 of the row pass above (ordinary loads, issued early)
+template <int I, int Q>
+__device__ __forceinline__ void pq_res32_issue(const PQArgs& g, int lane, int wave, int64_t m0, int64_t n0, f32x4 (&res)[8]) {
+  const int J = wave >> 2, rb = (wave & 3) * 32;
+  const int r2 = lane >> 5, c = lane & 31;
+  const float* rq = reinterpret_cast<const float*>(g.side) + (m0 + I * 128 + rb + r2) * g.lds + n0 + J * 128 + c * 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) res[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rq + (int64_t)(Q * 8 + k) * 2 * g.lds));
+}
+
+template <bool A_KS, bool B_KS, int MODE>
 __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   int tid = threadIdx.x;
@@ -316,18 +423,23 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   // per XCD, so that the tiles sharing an A row slab / B column slab sit behind one L2 (as in gemm_bf16_p8.hip)
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  // PQ_SLAB (split-K): the (K range, tile) units are ordered K-range-major, so that the tiles of ONE K range - which share
+  // its operand rows - sit behind one L2
   const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tcol = unit % g.nbx, trow = unit / g.nbx;
+  const int ksplit = MODE == PQ_SLAB ? unit / g.ntiles : 0;
+  const int tile = MODE == PQ_SLAB ? unit - ksplit * g.ntiles : unit;
+  const int tcol = tile % g.nbx, trow = tile / g.nbx;
   const int64_t m0 = (int64_t)trow * BT, n0 = (int64_t)tcol * BT;
-  const char* baseA = reinterpret_cast<const char*>(g.A + m0 * g.lda);
-  const char* baseB = reinterpret_cast<const char*>(B_KS ? g.B + n0 : g.B + n0 * g.ldb);
-  const int nk = g.K / BK;
-  const int64_t stepA = BK * 2;
+  const int64_t kb = MODE == PQ_SLAB ? (int64_t)ksplit * g.kper : 0;
+  const char* baseA = reinterpret_cast<const char*>(A_KS ? g.A + m0 + kb * g.lda : g.A + m0 * g.lda + kb);
+  const char* baseB = reinterpret_cast<const char*>(B_KS ? g.B + n0 + kb * g.ldb : g.B + n0 * g.ldb + kb);
+  const int nk = MODE == PQ_SLAB ? (int)((g.K - kb < g.kper ? g.K - kb : g.kper) / BK) : g.K / BK;
+  const int64_t stepA = A_KS ? (int64_t)BK * g.lda * 2 : BK * 2;
   const int64_t stepB = B_KS ? (int64_t)BK * g.ldb * 2 : BK * 2;
   const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void*)smem);
 
   // ---- side operands that travel during the K loop (oldest entries of the VM queue: the first counted wait covers them)
-  constexpr bool HAS_BIAS = MODE != PQ_DACT8;
+  constexpr bool HAS_BIAS = MODE == PQ_PLAIN || MODE == PQ_ACT8;   // bias added in the accumulator layout (PQ_RES: in the row pass)
   const bool has_bias = HAS_BIAS && g.bias != nullptr;
   if (has_bias)   // this wave's 2 x 32 columns: lane l -> column (l>>5)*128 + wc*32 + (l&31)
     dma4(g.bias + n0 + wc * 32, (uint32_t)(((lane >> 5) * 128 + (lane & 31)) * 4), lds0 + BIAS_OFF + wave * 256);
@@ -348,7 +460,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      offA[h][i] = off_direct(h, wave * 2 + i, lane, g.lda);
+      offA[h][i] = A_KS ? off_ks(h, wave * 2 + i, lane, g.lda) : off_direct(h, wave * 2 + i, lane, g.lda);
       offB[h][i] = B_KS ? off_ks(h, wave * 2 + i, lane, g.ldb) : off_direct(h, wave * 2 + i, lane, g.ldb);
     }
   const uint32_t lds_ring = lds0 + wave * 2048;
@@ -359,10 +471,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   for (int bf = 0; bf < 2; ++bf)
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      uint32_t oa = fragbase_direct(wr * 64, x, lane);
+      // k-strided A: one base per 32-row block (x = 0, 1), the k chunk is an immediate; direct A: one base per k chunk
+      uint32_t oa = A_KS ? fragbase_ks(wr * 64 + (x & 1) * 32, lane) : fragbase_direct(wr * 64, x, lane);
       uint32_t ob = B_KS ? fragbase_ks(wc * 32, lane) : fragbase_direct(wc * 32, x, lane);
       oa += bf * BUF; ob += bf * BUF;
-      asm volatile("" : "+v"(oa));
+      if (!A_KS || x < 2) asm volatile("" : "+v"(oa));
       if ((!B_KS || x < 1)) asm volatile("" : "+v"(ob));
       abase[bf][x] = sm3 + oa;
       bbase[bf][x] = sm3 + ob;
@@ -380,10 +493,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   typedef integral_constant<int, 1> I1;
   auto read_a = [&](auto bfc, auto uc) {
     constexpr int BF_ = decltype(bfc)::value, U = decltype(uc)::value;
-    fa[0][0] = frag_direct_at<U>(abase[BF_][0]); fa[0][1] = frag_direct_at<U>(abase[BF_][1]);
-    fa[0][2] = frag_direct_at<U>(abase[BF_][2]); fa[0][3] = frag_direct_at<U>(abase[BF_][3]);
-    fa[1][0] = frag_direct_at<U + 4096>(abase[BF_][0]); fa[1][1] = frag_direct_at<U + 4096>(abase[BF_][1]);
-    fa[1][2] = frag_direct_at<U + 4096>(abase[BF_][2]); fa[1][3] = frag_direct_at<U + 4096>(abase[BF_][3]);
+    if constexpr (A_KS) {
+      fa[0][0] = frag_ks_at<U + 0 * 4096>(abase[BF_][0]); fa[0][1] = frag_ks_at<U + 1 * 4096>(abase[BF_][0]);
+      fa[0][2] = frag_ks_at<U + 2 * 4096>(abase[BF_][0]); fa[0][3] = frag_ks_at<U + 3 * 4096>(abase[BF_][0]);
+      fa[1][0] = frag_ks_at<U + 0 * 4096>(abase[BF_][1]); fa[1][1] = frag_ks_at<U + 1 * 4096>(abase[BF_][1]);
+      fa[1][2] = frag_ks_at<U + 2 * 4096>(abase[BF_][1]); fa[1][3] = frag_ks_at<U + 3 * 4096>(abase[BF_][1]);
+    } else {
+      fa[0][0] = frag_direct_at<U>(abase[BF_][0]); fa[0][1] = frag_direct_at<U>(abase[BF_][1]);
+      fa[0][2] = frag_direct_at<U>(abase[BF_][2]); fa[0][3] = frag_direct_at<U>(abase[BF_][3]);
+      fa[1][0] = frag_direct_at<U + 4096>(abase[BF_][0]); fa[1][1] = frag_direct_at<U + 4096>(abase[BF_][1]);
+      fa[1][2] = frag_direct_at<U + 4096>(abase[BF_][2]); fa[1][3] = frag_direct_at<U + 4096>(abase[BF_][3]);
+    }
   };
   auto read_b = [&](auto bfc, auto uc, bf16x8_t (&fb)[4]) {
     constexpr int BF_ = decltype(bfc)::value, U = decltype(uc)::value;
@@ -472,6 +592,38 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   asm volatile("" : "+v"(lane));   // lane-dependent epilogue addresses are derived here, not kept live across the K loop
   const int li = lane & 31, lk = lane >> 5;
   lds_char* const smw = (lds_char*)smem;
+  if constexpr (MODE == PQ_SLAB || MODE == PQ_RES32) {
+    // fp32 output through fp32 patches: the partial tile of this K range -> its slab (PQ_SLAB), or
+    // (acc + bias) + fp32 residual -> fp32 (PQ_RES32: out_proj / c_proj on the fp32 residual stream)
+    constexpr bool RES = MODE == PQ_RES32;
+    float* const out = g.Cf + (int64_t)ksplit * g.slab_stride;
+    f32x4 ra[8], rb8[8], bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RES) {
+      pq_res32_issue<0, 0>(g, lane, wave, m0, n0, ra);
+      pq_res32_issue<0, 1>(g, lane, wave, m0, n0, rb8);
+      if (g.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n0 + (wave >> 2) * 128 + (lane & 31) * 4);
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#define PQ_BLOCKS32(I)                                                   \
+    do {                                                                 \
+      pq_block_f32<I, 0, 0>(smw, li, lk, wr, wc);                        \
+      pq_block_f32<I, 0, 1>(smw, li, lk, wr, wc);                        \
+      pq_block_f32<I, 1, 0>(smw, li, lk, wr, wc);                        \
+      pq_block_f32<I, 1, 1>(smw, li, lk, wr, wc);                        \
+      PQ_BAR_LDS();                                                      \
+    } while (0)
+    PQ_BLOCKS32(0);
+    pq_rows_q_f32<0, 0, RES>(g, out, sm3, lane, wave, m0, n0, ra, bias4);
+    if constexpr (RES) pq_res32_issue<1, 0>(g, lane, wave, m0, n0, ra);     // the second half's rows travel under the rest
+    pq_rows_q_f32<0, 1, RES>(g, out, sm3, lane, wave, m0, n0, rb8, bias4);
+    if constexpr (RES) pq_res32_issue<1, 1>(g, lane, wave, m0, n0, rb8);
+    PQ_BAR_LDS();
+    PQ_BLOCKS32(1);
+    pq_rows_q_f32<1, 0, RES>(g, out, sm3, lane, wave, m0, n0, ra, bias4);
+    pq_rows_q_f32<1, 1, RES>(g, out, sm3, lane, wave, m0, n0, rb8, bias4);
+#undef PQ_BLOCKS32
+    return;
+  }
   if constexpr (MODE == PQ_DACT8) side_half(1, SI1_OFF);   // lands under the first half's arithmetic
   f32x4 bias[2][4];
 #pragma unroll
@@ -483,48 +635,72 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   // MFMA results -> v_accvgpr_read: the last MFMA was issued a barrier ago; 16-pass XDL needs 18 wait states
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 
-#define PQ_HALF(I, SI)                                                         \
+  // PQ_RES: residual rows (both halves) and the bias of the row-pass chunk in registers
+  u32x4 res0[8], res1[8];
+  float bv[8];
+  if constexpr (MODE == PQ_RES) {
+    pq_res_issue<0>(g, lane, wave, m0, n0, res0);
+    const int cb = (wave >> 2) * 128 + ((wave & 1) * 8 + (lane & 7)) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[k] = g.bias != nullptr ? g.bias[n0 + cb + k] : 0.f;
+  }
+#define PQ_HALF(I, SI, RESV)                                                   \
   do {                                                                         \
     pq_block<MODE, I, 0, 0>(g, smw, bias[0], li, lk, wr, wc, SI);              \
     pq_block<MODE, I, 0, 1>(g, smw, bias[0], li, lk, wr, wc, SI);              \
     pq_block<MODE, I, 1, 0>(g, smw, bias[1], li, lk, wr, wc, SI);              \
     pq_block<MODE, I, 1, 1>(g, smw, bias[1], li, lk, wr, wc, SI);              \
     PQ_BAR_LDS();                                                              \
-    pq_rows_half<MODE, I>(g, sm3, lane, wave, m0, n0);                         \
+    if constexpr (MODE == PQ_RES) {                                            \
+      if (I == 0) pq_res_issue<1>(g, lane, wave, m0, n0, res1);                \
+      pq_rows_half_res<I>(g, sm3, lane, wave, m0, n0, RESV, bv);               \
+    } else {                                                                   \
+      pq_rows_half<MODE, I>(g, sm3, lane, wave, m0, n0);                       \
+    }                                                                          \
     if constexpr (MODE == PQ_ACT8) pq_rows_aux<I>(g, sm3, lane, wave, m0, n0); \
   } while (0)
-  PQ_HALF(0, SI0_OFF);
+  PQ_HALF(0, SI0_OFF, res0);
   // second half: its side-in pieces (4 per wave) are older than the first half's 8 output stores of this wave
   if constexpr (MODE == PQ_DACT8) { if (g.abl & 1) wait_vm<0>(); else wait_vm<8>(); }
   PQ_BAR_LDS();   // the patches are free again (and every wave's side-in pieces have landed)
-  PQ_HALF(1, SI1_OFF);
+  PQ_HALF(1, SI1_OFF, res1);
 #undef PQ_HALF
 }
 
 }  // namespace
 
-// The file is compiled once per PQ_PART (build.sh): 0 = forward layout, 1 = data-gradient layout, 2 = host dispatcher
+// The file is compiled once per PQ_PART (build.sh): 0 = forward layout, 1 = data-gradient layout, 2 = host dispatcher,
+// 3 = weight-gradient layout
 #ifndef PQ_PART
-#error "compile with -DPQ_PART=0..2 (see build.sh)"
+#error "compile with -DPQ_PART=0..3 (see build.sh)"
 #endif
-#define PQ_LAUNCH(BKS, MODE) hipLaunchKernelGGL((gemm_bf16_pq_kernel<BKS, MODE>), grid, dim3(NWV * 64), 0, stream, g)
+#define PQ_LAUNCH(AKS, BKS, MODE) hipLaunchKernelGGL((gemm_bf16_pq_kernel<AKS, BKS, MODE>), grid, dim3(NWV * 64), 0, stream, g)
 #if PQ_PART == 0
-void segclip_pq_launch_f(int mode, dim3 grid, hipStream_t stream, const void* args) {   // forward: plain / QuickGELU + saved derivative
+void segclip_pq_launch_f(int mode, dim3 grid, hipStream_t stream, const void* args) {   // forward: plain / QuickGELU + saved derivative / + residual
   const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
-  if (mode == PQ_ACT8) PQ_LAUNCH(false, PQ_ACT8);
-  else PQ_LAUNCH(false, PQ_PLAIN);
+  if (mode == PQ_ACT8) PQ_LAUNCH(false, false, PQ_ACT8);
+  else if (mode == PQ_RES) PQ_LAUNCH(false, false, PQ_RES);
+  else if (mode == PQ_RES32) PQ_LAUNCH(false, false, PQ_RES32);
+  else PQ_LAUNCH(false, false, PQ_PLAIN);
 }
 #elif PQ_PART == 1
 void segclip_pq_launch_k(int mode, dim3 grid, hipStream_t stream, const void* args) {   // data gradient: plain / x saved derivative
   const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
-  if (mode == PQ_DACT8) PQ_LAUNCH(true, PQ_DACT8);
-  else PQ_LAUNCH(true, PQ_PLAIN);
+  if (mode == PQ_DACT8) PQ_LAUNCH(false, true, PQ_DACT8);
+  else PQ_LAUNCH(false, true, PQ_PLAIN);
+}
+#elif PQ_PART == 3
+void segclip_pq_launch_w(int mode, dim3 grid, hipStream_t stream, const void* args) {   // weight gradient: both operands k-strided, fp32 slabs
+  const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
+  (void)mode;
+  PQ_LAUNCH(true, true, PQ_SLAB);
 }
 #endif
 
 #if PQ_PART == 2
 void segclip_pq_launch_f(int, dim3, hipStream_t, const void*);
 void segclip_pq_launch_k(int, dim3, hipStream_t, const void*);
+void segclip_pq_launch_w(int, dim3, hipStream_t, const void*);
 
 // Launch this kernel when the problem meets its preconditions (see the top of the file); false = not taken.
 bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t nb, hipStream_t stream) {
@@ -534,11 +710,53 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   if (mode_env == 2) { const char* e = getenv("SEGCLIP_GEMM_PQ_NOW"); if (e && atoi(e) == 0) return false; }
   const Args& a = *reinterpret_cast<const Args*>(args_);
   const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
-  if (a_ks || splits != 1 || nb != 1) return false;
-  if (d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16 || d->c_dtype != SEGCLIP_BF16) return false;
+  if (nb != 1 || d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16) return false;
   if (d->M % BT != 0 || d->N % BT != 0 || d->K % BK != 0 || d->K < BK) return false;
-  if (d->alpha != 1.0f || d->residual != nullptr) return false;
+  if (a_ks) {   // weight gradient: C(m,n) = sum_k A[k][m] B[k][n], fp32 out (split-K: raw partial tiles into the slabs)
+    static const int wg_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ_WGRAD"); return e ? atoi(e) : 1; }();
+    if (!wg_env || !b_ks || d->c_dtype != SEGCLIP_F32) return false;
+    if (d->bias || d->residual || d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact || a.colsum_part) return false;
+    if (splits == 1 && (d->alpha != 1.0f || d->ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(d->C) & 15) != 0)) return false;
+    if (splits > 1 && (a.slab == nullptr || a.kper % BK != 0 || d->N % 4 != 0 || (reinterpret_cast<uintptr_t>(a.slab) & 15) != 0)) return false;
+    if ((reinterpret_cast<uintptr_t>(d->A) & 15) != 0 || (reinterpret_cast<uintptr_t>(d->B) & 15) != 0) return false;
+    if (d->sak % 8 != 0 || d->sbk % 8 != 0) return false;
+    if (64 * d->sak * 2 >= (int64_t)1 << 31 || 64 * d->sbk * 2 >= (int64_t)1 << 31) return false;
+    PQArgs g = {};
+    g.A = reinterpret_cast<const bf16_t*>(d->A); g.B = reinterpret_cast<const bf16_t*>(d->B);
+    g.lda = d->sak; g.ldb = d->sbk;
+    g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
+    if (splits > 1) { g.Cf = a.slab; g.ldc = d->N; g.kper = a.kper; g.slab_stride = d->M * d->N; }
+    else { g.Cf = reinterpret_cast<float*>(d->C); g.ldc = d->ldc; g.kper = d->K; g.slab_stride = 0; }
+    if (256 * g.ldc * 4 >= (int64_t)1 << 31) return false;
+    { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
+    segclip_pq_launch_w(PQ_SLAB, dim3((unsigned)(g.ntiles * splits)), stream, &g);
+    return true;
+  }
+  if (splits != 1) return false;
+  if (d->c_dtype == SEGCLIP_F32) {   // forward + fp32 residual -> fp32 (the fp32 residual stream): fp32 patches, fp32 row pass
+    static const int r32_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ_RES32"); return e ? atoi(e) : 1; }();
+    if (!r32_env || b_ks || d->residual == nullptr || d->r_dtype != SEGCLIP_F32 || d->alpha != 1.0f) return false;
+    if (d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact || a.colsum_part) return false;
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al16(d->A) || !al16(d->B) || !al16(d->C) || !al16(d->bias) || !al16(d->residual)) return false;
+    if (d->sam % 8 != 0 || d->sbn % 8 != 0 || d->ldc % 4 != 0 || d->ldr % 4 != 0) return false;
+    if (256 * d->sam * 2 >= (int64_t)1 << 31 || 256 * d->sbn * 2 >= (int64_t)1 << 31 || 256 * d->ldc * 4 >= (int64_t)1 << 31) return false;
+    PQArgs g = {};
+    g.A = reinterpret_cast<const bf16_t*>(d->A); g.B = reinterpret_cast<const bf16_t*>(d->B);
+    g.bias = d->bias; g.side = d->residual; g.lds = d->ldr;
+    g.lda = d->sam; g.ldb = d->sbn; g.Cf = reinterpret_cast<float*>(d->C); g.ldc = d->ldc;
+    g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
+    { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
+    segclip_pq_launch_f(PQ_RES32, dim3((unsigned)g.ntiles), stream, &g);
+    return true;
+  }
+  if (d->c_dtype != SEGCLIP_BF16) return false;
+  if (d->alpha != 1.0f) return false;
   int mode = PQ_PLAIN;
+  if (d->residual != nullptr) {   // + bf16 residual -> bf16 (the bf16 residual stream of the towers): forward layout only
+    if (d->r_dtype != SEGCLIP_BF16 || b_ks || d->mul_dact || d->act != SEGCLIP_ACT_NONE || d->aux || d->ldr % 8 != 0) return false;
+    mode = PQ_RES;
+  } else
   if (d->mul_dact) {            // x act'(u), saved as one byte; optional fused column sums
     if (!(d->aux && d->aux_kind == 2 && d->act == SEGCLIP_ACT_QUICK_GELU && !d->bias && b_ks && d->ldaux % 16 == 0)) return false;
     mode = PQ_DACT8;
@@ -550,19 +768,19 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   }
   if (a.colsum_part != nullptr && mode != PQ_DACT8) return false;
   auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (!al(d->A) || !al(d->B) || !al(d->C) || !al(d->bias) || !al(d->aux) || d->ldc % 8 != 0) return false;
+  if (!al(d->A) || !al(d->B) || !al(d->C) || !al(d->bias) || !al(d->aux) || !al(d->residual) || d->ldc % 8 != 0) return false;
   const int64_t lda = d->sam, ldb = b_ks ? d->sbk : d->sbn;
   if (lda % 8 != 0 || ldb % 8 != 0) return false;
   // 32-bit per-lane offsets: 256 rows (64 k-rows) of an operand and 256 rows of an output stay below 2 GiB
   if (256 * lda * 2 >= (int64_t)1 << 31 || (b_ks ? 64 : 256) * ldb * 2 >= (int64_t)1 << 31) return false;
   if (256 * d->ldc * 2 >= (int64_t)1 << 31 || 256 * d->ldaux >= (int64_t)1 << 31) return false;
-  PQArgs g;
+  PQArgs g = {};
   g.A = reinterpret_cast<const bf16_t*>(d->A); g.B = reinterpret_cast<const bf16_t*>(d->B);
   g.C = reinterpret_cast<bf16_t*>(d->C); g.bias = d->bias;
-  g.side = mode == PQ_DACT8 ? d->aux : nullptr;
+  g.side = mode == PQ_DACT8 ? d->aux : (mode == PQ_RES ? d->residual : nullptr);
   g.aux = mode == PQ_ACT8 ? reinterpret_cast<uint8_t*>(d->aux) : nullptr;
   g.colsum_part = a.colsum_part;
-  g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = d->ldaux; g.ldaux = d->ldaux;
+  g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = mode == PQ_RES ? d->ldr : d->ldaux; g.ldaux = d->ldaux;
   g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
   { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
   (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3((unsigned)g.ntiles), stream, &g);

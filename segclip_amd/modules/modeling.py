@@ -180,9 +180,12 @@ class SegCLIP(SegCLIPPreTrainedModel):
                 config.set_stack_hook(k, enqueue_text)
             else:
                 enqueue_text()
-            visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
-                                                                              return_hidden=True)
-            pending = config.take_stack_hook()      # a vision tower without a fused stack never ran the hook
+            pending = None
+            try:
+                visual_output, mid_states = self.clip.encode_image_pooled(image)
+                pending = config.take_stack_hook()      # a vision tower without a fused stack never ran the hook
+            finally:
+                config.take_stack_hook()                # never leave a stale hook behind an exception
             if pending is not None:
                 pending[1]()
             sequence_output = box["seq"]
@@ -190,16 +193,14 @@ class SegCLIP(SegCLIPPreTrainedModel):
             sequence_output.record_stream(main)
         else:
             sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
-            visual_output, visual_hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame,
-                                                                              return_hidden=True)
+            visual_output, mid_states = self.clip.encode_image_pooled(image)
         self.last_mid_states = _detached(mid_states)
-        sim_matrix_t2v, sim_matrix_v2t = self._loose_similarity(sequence_output, visual_output)
-        offset = sequence_output.size(0) * int(getattr(self.task_config, "rank", 0))
-        sim_loss1 = ops.CrossEntropyFn.apply(sim_matrix_t2v, offset)
-        sim_loss2 = ops.CrossEntropyFn.apply(sim_matrix_v2t, offset)
-        loss = (sim_loss1 + sim_loss2) / 2.
+        # contrastive head (modules/modeling.py:196-210,338-362) as one autograd node: L2-normalise, one stacked all-gather,
+        # both logits matrices in exact fp32, both cross entropies, their mean
+        self._last_head = {}
+        loss = ops.ClipLossFn.apply(visual_output.float().view(b, -1), sequence_output.squeeze(1).float(), self.clip.logit_scale,
+                                    int(getattr(self.task_config, "rank", 0)), self._last_head)
         self.last_losses = {"contrastive": loss.detach()}
-        self.last_logits = (sim_matrix_t2v.detach(), sim_matrix_v2t.detach())
         if self.use_seglabel:
             image_seg_ = torch.as_tensor(image_seg)[:, 0].reshape(b, -1)
             hard = mid_states["attns"][0]["hard_attn"]
@@ -232,6 +233,16 @@ class SegCLIP(SegCLIPPreTrainedModel):
             loss = loss + vis_mae_loss
             self.last_losses["mae"] = vis_mae_loss.detach()
         return loss
+
+    @property
+    def last_logits(self):
+        """(sim_matrix_t2v, sim_matrix_v2t) of the last training forward (inspection only; computed on demand from the raw
+        cosines the fused contrastive head keeps)."""
+        h = getattr(self, "_last_head", None)
+        if not h:
+            return None
+        s = torch.clamp(h["logit_scale"].exp(), max=100)
+        return s * h["cos"][0], s * h["cos"][1]
 
     def get_sequence_output(self, input_ids, token_type_ids, attention_mask, shaped=False, return_hidden=False,
                             seq_model=None, mask_ratio=0.):

@@ -57,6 +57,16 @@ class CLIP(CLIP_Module):
             return x, hidden, mid_states
         return x
 
+    def encode_image_pooled(self, image):
+        """Training fast path of encode_image (modules/module_clip.py:89-103): only the pooled feature the contrastive loss
+        uses.  ln_post and the projection are per-row operations, so applying them to the max-pooled row alone gives the
+        same values as hidden[:, 0, :] of the full path, without normalising / projecting (and back-propagating zeros
+        through) the other 196 rows.  -> (feature (B, embed_dim) fp32, mid_states)"""
+        cls, _, _, mid_states = self.visual(image.type(self.dtype), pooled_only=True)
+        h = self.visual.ln_post(cls)
+        x = ops.linear(h, self.visual.proj, None, out_dtype=torch.float32, act_dtype=config.compute_dtype, w_kn=True)
+        return x, mid_states
+
     def _text_trunk(self, text):
         x = ops.EmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
         return self.transformer.forward_nld(x, causal=True)

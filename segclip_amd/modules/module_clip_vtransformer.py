@@ -45,7 +45,8 @@ class VisualTransformer(nn.Module):
             cache[key] = ops.interp_pos_table(self.positional_embedding, h_, w_)
         return cache[key]
 
-    def forward(self, x: torch.Tensor, video_frame=-1, mask_ratio=0.):
+    def forward(self, x: torch.Tensor, video_frame=-1, mask_ratio=0., pooled_only=False):
+        """pooled_only (mask_ratio == 0 only): returns (cls (B, D), None, None, mid_states) - see SegViT.forward_patches"""
         B, _, H, W = x.shape
         h_, w_ = H // self.patch_size, W // self.patch_size
         pos = self.get_pos_embed(h_, w_)
@@ -63,7 +64,9 @@ class VisualTransformer(nn.Module):
             ids_shuffle, mae_ids_restore, mae_mask = ops.mask_sort(noise, len_keep)
             keep = (ids_shuffle[:, 1:len_keep] - 1).contiguous()
             xp = ops.GatherRowsFn.apply(xp, keep)
-        x, mid_states = self.transformer.forward_patches(xp)
+        if pooled_only and mask_ratio > 0.:
+            raise ValueError("pooled_only is the main (unmasked) branch's fast path")
+        x, mid_states = self.transformer.forward_patches(xp, pooled_only=pooled_only)
         if len(mid_states["attns"]) == 0:
             assert mask_ratio > 0., "Must pass the semantic layer~"
         return x, mae_mask, mae_ids_restore, mid_states

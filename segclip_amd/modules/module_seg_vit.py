@@ -6,6 +6,7 @@ import torch
 from torch import nn
 from torch.nn.parameter import Parameter
 
+from .. import _lib as L
 from .. import config, ops
 from .module_clip_util import LayerNorm, QuickGELU
 
@@ -139,6 +140,70 @@ class GroupLinearFn(torch.autograd.Function):
         return dx, dw, None
 
 
+def _gl64(ins, outs, ws, M, groups):
+    """segclip_group_linear64: out_o = sum_i in_i x ws[i * len(outs) + o] per 64-channel group (bf16 rows)."""
+    import ctypes as C
+    L.require_cuda(*ins, *outs, *ws)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    lds = lambda ts: (C.c_int64 * len(ts))(*[t.stride(0) for t in ts])
+    L.check(L.load().segclip_group_linear64(C.cast(arr(ins), C.c_void_p), C.cast(lds(ins), C.c_void_p), len(ins),
+                                            C.cast(arr(outs), C.c_void_p), C.cast(lds(outs), C.c_void_p), len(outs),
+                                            C.cast(arr(ws), C.c_void_p), M, groups, L.stream()), "group_linear64")
+
+
+class GroupLinearPairFn(torch.autograd.Function):
+    """k_conv and v_conv of the learnable-center stage (two grouped kernel-1 Conv1d's of the SAME input,
+    modules/module_seg_vit.py:299,302) as ONE pass over the rows, and their data gradient dn = dk Wk + dv Wv as one
+    pass (segclip_group_linear64; bf16 mode, 64 channels per group).  Weight gradients: the batched GEMM path."""
+
+    @staticmethod
+    def forward(ctx, x, wk, wv, groups):
+        M, D = x.shape
+        hd = D // groups
+        wkc, wvc = ops.wcast(wk.reshape(D, hd), x.dtype), ops.wcast(wv.reshape(D, hd), x.dtype)
+        k, v = torch.empty_like(x), torch.empty_like(x)
+        _gl64((x,), (k, v), (wkc, wvc), M, groups)
+        ctx.save_for_backward(x, wkc, wvc)
+        ctx.groups, ctx.wshape = groups, tuple(wk.shape)
+        return k, v
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        x, wkc, wvc = ctx.saved_tensors
+        M, D = x.shape
+        G = ctx.groups
+        hd = D // G
+        dk, dv = dk.contiguous(), dv.contiguous()
+        dx = dwk = dwv = None
+        if ctx.needs_input_grad[0]:
+            # per-group transposed weights (96 KiB each): dn(m, g*64 + k) = sum_n dk(m, g*64 + n) Wk[g*64 + n][k] + (same, v)
+            wkt = wkc.view(G, hd, hd).transpose(1, 2).contiguous().view(D, hd)
+            wvt = wvc.view(G, hd, hd).transpose(1, 2).contiguous().view(D, hd)
+            dx = torch.empty_like(x)
+            _gl64((dk, dv), (dx,), (wkt, wvt), M, G)
+        for need, dy, name in ((ctx.needs_input_grad[1], dk, "k"), (ctx.needs_input_grad[2], dv, "v")):
+            if need:
+                dw = torch.empty((D, hd), dtype=torch.float32, device=x.device)
+                ops.p_gemm(dy, x, dw, hd, hd, M, (1, D), (1, D), hd, nb1=G, bsA=(hd, 0), bsB=(hd, 0), bsC=(hd * hd, 0))
+                if name == "k":
+                    dwk = dw.view(ctx.wshape)
+                else:
+                    dwv = dw.view(ctx.wshape)
+        return dx, dwk, dwv, None
+
+
+_GL64 = __import__("os").environ.get("SEGCLIP_GL64", "1") != "0"   # 0: the two batched-GEMM launches (A/B tests)
+
+
+def _group_linear_pair(n2d, wk, wv, groups):
+    """(k_conv(n), v_conv(n)) on channel-last rows; one fused pass in bf16 mode with 64-channel groups."""
+    M, D = n2d.shape
+    if (_GL64 and n2d.dtype == torch.bfloat16 and D // groups == 64 and n2d.stride(1) == 1 and n2d.stride(0) % 8 == 0
+            and n2d.data_ptr() % 16 == 0):
+        return GroupLinearPairFn.apply(n2d, wk, wv, groups)
+    return _group_linear(n2d, wk, groups), _group_linear(n2d, wv, groups)
+
+
 class SemanticLearnerModule(nn.Module):
     """modules/module_seg_vit.py:244-314: learnable centers -> cross attention x2 -> hard (Gumbel)
     assignment of every patch to one center -> segment mean -> proj_o."""
@@ -174,9 +239,9 @@ class SemanticLearnerModule(nn.Module):
             q = blk(q, kv)
         q = ops.layer_norm(q, self.cross_ln.weight, self.cross_ln.bias, self.cross_ln.eps, torch.float32)
         n2 = n.view(B * T, D)
-        k = _group_linear(n2, self.k_conv.weight, self.num_heads)
+        k, v = _group_linear_pair(n2, self.k_conv.weight, self.v_conv.weight, self.num_heads)
         k = ops.layer_norm(k, self.k_ln.weight, self.k_ln.bias, self.k_ln.eps, torch.float32).view(B, T, D)
-        v = _group_linear(n2, self.v_conv.weight, self.num_heads).view(B, T, D)
+        v = v.view(B, T, D)
         # assignment logits always in exact fp32 (bit-exact argmax), un-scaled (module_seg_vit.py:304)
         attn = ops.bmm(q, k, transB=True, out_dtype=torch.float32)
         g = config.gumbel((B, G, T), inputs.device) if self.training else None
@@ -252,13 +317,16 @@ class SegViT(nn.Module):
                 and all(isinstance(b, ResidualAttentionBlock) and not b.causal for b in blocks)):
             b0 = blocks[0]
 
-            def stack(bs, t):
+            def stack(bs, t, keep16=False):
                 if len(bs) == 1:
-                    return bs[0](t)
-                return ops.res_stack(t.float(), [b.block_params() for b in bs], b0.n_head, False, ops.ACT_QUICK_GELU,
-                                     b0.ln_1.eps, config.compute_dtype)
+                    return bs[0](t.float())
+                if t.dtype != torch.bfloat16:      # (a bf16 stream handed over by the previous stack stays as it is)
+                    t = t.float()
+                return ops.res_stack(t, [b.block_params() for b in bs], b0.n_head, False, ops.ACT_QUICK_GELU,
+                                     b0.ln_1.eps, config.compute_dtype, keep16=keep16)
             if hook is not None and 0 < hook[0] < len(blocks):
-                x = stack(blocks[:hook[0]], x)
+                # config.bf16_resid: the two parts exchange the bf16 residual stream directly (no fp32 round trip)
+                x = stack(blocks[:hook[0]], x, keep16=len(blocks) - hook[0] > 1)
                 hook[1]()
                 return stack(blocks[hook[0]:], x)
             if hook is not None:
@@ -268,9 +336,10 @@ class SegViT(nn.Module):
             hook[1]()
         return seq(x)
 
-    def forward_patches(self, x_):
+    def forward_patches(self, x_, pooled_only=False):
         """Body of forward() on the patch tokens only: x_ (B,T,D) NLD without the CLS row.
-        Returns (x (B,1+T',D) NLD with the pooled CLS prepended, mid_states)."""
+        Returns (x (B,1+T',D) NLD with the pooled CLS prepended, mid_states); pooled_only (the training step's fast path, main
+        branch only): (cls (B,D), mid_states) - the max over the tokens alone, without building the (B,1+T',D) tensor."""
         mid_states = {"hidden": None, "attns": []}
         x_ = self._run_blocks(self.layers0, x_)
         if self.patch_len ** 2 != x_.size(1) and 4 * (self.patch_len ** 2) != x_.size(1):  # MAE branch
@@ -284,9 +353,12 @@ class SegViT(nn.Module):
             mid_states["hidden"] = x_
             x_, hard_attn_2, soft_attn_2, _ = self.semantic_layer2(x_)
             x_ = self._run_blocks(self.layers2, x_)
+            mid_states["attns"].append({"soft_attn": soft_attn_2, "hard_attn": hard_attn_2})
+            if pooled_only:
+                mid_states["hard_idx"] = self.semantic_layer2.last_hard_idx
+                return ops.MaxTokensFn.apply(x_.float(), config.compute_dtype == torch.bfloat16), mid_states
             cls = torch.max(x_, dim=1, keepdim=True)[0]
             x = torch.cat([cls, x_], dim=1)
-            mid_states["attns"].append({"soft_attn": soft_attn_2, "hard_attn": hard_attn_2})
         mid_states["hard_idx"] = self.semantic_layer2.last_hard_idx
         return x, mid_states
 

@@ -218,9 +218,18 @@ def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_d
     y = alloc((M, N), out_dtype, x)
     aux = alloc((M, N), torch.uint8 if aux_kind == 2 else out_dtype, x) if (want_aux and act != ACT_NONE) else None
     sb = (1, w.stride(0)) if w_kn else (w.stride(0), 1)
-    p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, _ld(y), bias=bias, residual=residual,
-           ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux) if aux is not None else N, act=act,
-           aux_kind=aux_kind)
+    try:
+        p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, _ld(y), bias=bias, residual=residual,
+               ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux) if aux is not None else N, act=act,
+               aux_kind=aux_kind)
+    except L.Unsupported:
+        if aux_kind != 2 or aux is None:
+            raise
+        # the one-byte derivative needs full 256 x 256 tiles and 16-byte aligned operands (include/segclip_hip.h): keep it
+        # as bf16 instead (aux_kind 1); the backward reads the form off the tensor's dtype
+        aux = alloc((M, N), out_dtype, x)
+        p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, _ld(y), bias=bias, residual=residual,
+               ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux), act=act, aux_kind=1)
     return y, aux
 
 
@@ -613,7 +622,8 @@ class ActFn(Function):
 
 
 def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
-    """One pre-LN residual block on the (B*T, D) fp32 stream: returns (x_out (B*T, D) fp32, tensors saved for backward)."""
+    """One pre-LN residual block on the (B*T, D) residual stream x2 - fp32, or bf16 inside a ResStackFn running with
+    config.bf16_resid - : returns (x_out (B*T, D) in the stream's dtype, tensors saved for backward)."""
     ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = P
     M, D = x2.shape
     hd = D // n_head
@@ -630,12 +640,12 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
                     (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D,
                     fp8=bool(_cfg.attn_fp8) and act_dtype == torch.bfloat16, klen=klen)
     stats = p_attn_fwd(ad, x2)
-    x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=torch.float32)
+    x1, _ = p_linear(o, wo_c, bo, residual=x2, out_dtype=x2.dtype)
     y2, mean2, rstd2 = p_ln_fwd(x1, ln2w, ln2b, eps, act_dtype)
     # bf16 mode: the c_fc epilogue stores act'(u) (its exponential is already there), the c_proj dgrad multiplies by it
     h, u = p_linear(y2, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act, y2.shape[0], wfc_c.shape[0]),
                     pitched=act_dtype == torch.bfloat16)
-    xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=torch.float32)
+    xo, _ = p_linear(h, wpr_c, bpr, residual=x1, out_dtype=x2.dtype)
     saved = (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c)
     return xo, saved
 
@@ -643,15 +653,14 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
 N_SAVED = 19
 
 
-_AUX_U8 = os.environ.get("SEGCLIP_AUX_U8", "1") != "0"
-
-
 def _aux_kind(act_dtype, act, M=0, N=0):
     """What the residual blocks keep of the MLP pre-activation: act'(u) in bf16 mode with QuickGELU (the towers) - as one
-    byte per element (aux_kind 2: half the bytes of the block's largest side tensor) when the GEMM runs on full 256 x 256
-    tiles, else as bf16 -, u itself in the exact-f32 mode and for the erf-GELU of the MAE decoders."""
+    byte per element (aux_kind 2, config.aux_u8: half the bytes of the block's largest side tensor; absolute error
+    <= 0.0025) when the GEMM runs on full 256 x 256 tiles, else as bf16 -, u itself in the exact-f32 mode and for the
+    erf-GELU of the MAE decoders."""
     if act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU:
-        return 2 if (_AUX_U8 and M > 0 and M % 256 == 0 and N % 256 == 0) else 1
+        from . import config as _cfg
+        return 2 if (_cfg.aux_u8 and M > 0 and M % 256 == 0 and N % 256 == 0) else 1
     return 0
 
 
@@ -788,15 +797,25 @@ class ResStackFn(Function):
     node's own input / output gradients stay fp32.  With segclip_amd.dist.GradSync active, each block's parameter
     gradients are published (p.grad = bucket slot, ready hook) as soon as the block's backward has been enqueued, not
     when the whole stack returns, so the bucket all-reduces keep overlapping with the rest of the backward.
-    inputs: x, n_head, causal, act, eps, act_dtype, klen, chain, then 12 parameters per block."""
+    inputs: x, n_head, causal, act, eps, act_dtype, klen, chain, keep16, then 12 parameters per block."""
 
     NP = 12
 
     @staticmethod
-    def forward(ctx, x, n_head, causal, act, eps, act_dtype, klen, chain, *params):
+    def forward(ctx, x, n_head, causal, act, eps, act_dtype, klen, chain, keep16, *params):
         B, T, D = x.shape
         nblk = len(params) // ResStackFn.NP
         cur = x.contiguous().view(B * T, D)
+        from . import config as _cfg
+        # config.bf16_resid (bf16 mode): the residual stream is bf16 between the blocks of the stack (the out_proj / c_proj
+        # epilogues read and write 2 instead of 4 bytes per element and run on gemm_bf16_pq.hip; every LayerNorm pass reads
+        # 2 bytes less).  Input / output of the node: fp32, or bf16 when the neighbouring node is a stack too (keep16).
+        ctx.in_dtype = x.dtype
+        resid16 = act_dtype == torch.bfloat16 and (bool(_cfg.bf16_resid) or x.dtype == torch.bfloat16)
+        if resid16 and cur.dtype != torch.bfloat16:
+            cur = p_cast(cur, torch.bfloat16)
+        elif not resid16 and cur.dtype != torch.float32:
+            cur = p_cast(cur, torch.float32)
         saved = []
         for b in range(nblk):
             cur, sv = _resblock_fwd(cur, params[b * 12:(b + 1) * 12], B, T, n_head, causal, act, eps, act_dtype, klen)
@@ -804,11 +823,12 @@ class ResStackFn(Function):
         ctx.save_for_backward(*saved)
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
         ctx.klen, ctx.nblk = klen, nblk
-        ctx.chain = bool(chain) and act_dtype == torch.bfloat16
-        from . import config as _cfg
+        ctx.chain = (bool(chain) or resid16) and act_dtype == torch.bfloat16
         ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
         ctx.params = params
         ctx.slots = tuple(_slot_of(w) for w in params)
+        if resid16 and not keep16:
+            cur = p_cast(cur, torch.float32)
         return cur.view(B, T, D)
 
     @staticmethod
@@ -821,9 +841,11 @@ class ResStackFn(Function):
             st = None
         g = g.contiguous().view(M, D)
         cur16 = st.view(M, D) if (st is not None and bf) else None
+        if bf and cur16 is None and g.dtype == torch.bfloat16:   # bf16 output of the node (keep16)
+            cur16 = g
         if ctx.chain and cur16 is None:
             cur16 = p_cast(g, act_dtype)
-        cur32 = None if ctx.chain else g
+        cur32 = None if ctx.chain else (g if g.dtype == torch.float32 else p_cast(g, torch.float32))
         saved = ctx.saved_tensors
         need_all = ctx.needs_input_grad
         out = [None] * (nblk * 12)
@@ -831,7 +853,7 @@ class ResStackFn(Function):
         for b in reversed(range(nblk)):
             P = ctx.params[b * 12:(b + 1) * 12]
             sl = ctx.slots[b * 12:(b + 1) * 12]
-            need = (True,) + tuple(need_all[8 + b * 12 + i] for i in range(12))
+            need = (True,) + tuple(need_all[9 + b * 12 + i] for i in range(12))
             gslots = (sl[2], sl[4], sl[8], sl[10])
             vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
             cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
@@ -849,21 +871,25 @@ class ResStackFn(Function):
         if keep is not None:
             torch.cuda.current_stream().wait_stream(_wgrad_stream())
             keep.clear()
-        if ctx.chain:
+        if ctx.chain and ctx.in_dtype == torch.bfloat16:
+            dx = cur16                       # the producer is a stack with a bf16 output: no cast, no side copy
+        elif ctx.chain:
             dx = p_cast(cur16, torch.float32)
         else:
             dx = cur32
         dx = dx.view(B, T, D)
-        if cur16 is not None:
+        if cur16 is not None and dx.dtype != torch.bfloat16:
             dx._segclip_bf16 = cur16.view(B, T, D)
-        return (dx, None, None, None, None, None, None, None) + tuple(out)
+        return (dx, None, None, None, None, None, None, None, None) + tuple(out)
 
 
-def res_stack(x, blocks_params, n_head, causal, act, eps, act_dtype, klen=None):
-    """Run consecutive residual blocks (each a 12-tuple of parameters in ResBlockFn order) as one ResStackFn node."""
+def res_stack(x, blocks_params, n_head, causal, act, eps, act_dtype, klen=None, keep16=False):
+    """Run consecutive residual blocks (each a 12-tuple of parameters in ResBlockFn order) as one ResStackFn node.
+    keep16 (config.bf16_resid only): hand the bf16 residual stream to the caller as it is - for the next stack."""
     from . import config as _cfg
     flat = [p for P in blocks_params for p in P]
-    return ResStackFn.apply(x, n_head, causal, act, eps, act_dtype, klen, bool(_cfg.bf16_resgrad), *flat)
+    keep16 = bool(keep16) and bool(_cfg.bf16_resid) and act_dtype == torch.bfloat16
+    return ResStackFn.apply(x, n_head, causal, act, eps, act_dtype, klen, bool(_cfg.bf16_resgrad), keep16, *flat)
 
 
 class CrossAttnFn(Function):
@@ -1136,21 +1162,21 @@ def prefix_mask_lengths(attention_mask):
     """(B, L) 0/1 attention mask of END-PADDED captions (the dataloader contract, dataloaders/dataloader_cc_retrieval.py:
     valid tokens first) -> int32 (B,) number of valid keys, the form the attention kernels take the key-padding mask in.
     The prefix form (no interior zeros, no left padding, at least one valid key per row - a row without keys has
-    lse = -inf) is VALIDATED on the first call of the process and on every call with SEGCLIP_CHECK_MASKS=1 (one host
-    synchronisation); other masks raise instead of silently attending to the wrong keys."""
+    lse = -inf) is checked ON EVERY CALL without a host synchronisation: the verdict is computed on the device and
+    handed to torch._assert_async, which fails the stream (the error surfaces at the next synchronisation) instead of
+    silently attending to the wrong keys.  SEGCLIP_CHECK_MASKS=1 additionally raises at the call site (one host sync)."""
     m = attention_mask.reshape(attention_mask.shape[0], -1)
-    global _MASK_CHECKED
-    if not _MASK_CHECKED or _CHECK_MASKS:
-        _MASK_CHECKED = True
-        mi = m.to(torch.int32)
-        ok = bool(((mi[:, 1:] <= mi[:, :-1]).all() & (mi[:, 0] >= 1).all() & ((mi == 0) | (mi == 1)).all()).item())
-        if not ok:
+    mi = m.to(torch.int32)
+    ok = (mi[:, 1:] <= mi[:, :-1]).all() & (mi[:, 0] >= 1).all() & ((mi == 0) | (mi == 1)).all()
+    if _CHECK_MASKS or not mi.is_cuda:
+        if not bool(ok.item()):
             raise NotImplementedError("attention_mask must be a 0/1 PREFIX mask with >= 1 valid token per row "
                                       "(end-padded captions); interior zeros / left padding are not supported")
-    return m.to(torch.int32).sum(dim=1, dtype=torch.int32).contiguous()
+    else:
+        torch._assert_async(ok, "segclip: attention_mask is not a 0/1 prefix mask (interior zeros / left padding / empty row)")
+    return mi.sum(dim=1, dtype=torch.int32).contiguous()
 
 
-_MASK_CHECKED = False
 _CHECK_MASKS = bool(int(__import__("os").environ.get("SEGCLIP_CHECK_MASKS", "0")))
 
 
@@ -1270,6 +1296,46 @@ class _on_comm_stream:
         return False
 
 
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _gather_raw(x, world):
+    """rank-ordered all-gather of (B, ...) -> (B * world, ...), no autograd.  world 0 (no process group): identity."""
+    if world == 0:
+        return x
+    x = x.contiguous()
+    if x.is_cuda and dist.get_backend() != "nccl":
+        # gloo has no device all-gather (only broadcast / all-reduce take GPU tensors): the single-GPU
+        # multi-process tests gather by summing rank-disjoint slices, which is exact
+        out = torch.zeros((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        r = dist.get_rank()
+        out[r * x.shape[0]:(r + 1) * x.shape[0]] = x
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    with _on_comm_stream(x):
+        dist.all_gather_into_tensor(out, x)
+    return out
+
+
+def _scatter_sum_raw(g, world):
+    """the adjoint: reduce-scatter(SUM) of (B * world, ...) -> this rank's (B, ...), no autograd"""
+    if world == 0:
+        return g
+    g = g.contiguous()
+    n = g.shape[0] // world
+    if dist.get_backend() == "nccl":
+        out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        with _on_comm_stream(g):
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
+        return out
+    g = g.clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    r = dist.get_rank()
+    return g[r * n:(r + 1) * n].contiguous()
+
+
 class AllGatherFn(Function):
     """Differentiable rank-ordered all-gather of (B, ...) embeddings (dist_collect,
     modules/util_module.py:180-190; diffdist semantics: all_gather forward, reduce-scatter(SUM)
@@ -1278,39 +1344,108 @@ class AllGatherFn(Function):
 
     @staticmethod
     def forward(ctx, x):
-        ctx.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0
-        if ctx.world == 0:   # no process group: single-process run, identity
-            return x
-        x = x.contiguous()
-        if x.is_cuda and dist.get_backend() != "nccl":
-            # gloo has no device all-gather (only broadcast / all-reduce take GPU tensors): the single-GPU
-            # multi-process tests gather by summing rank-disjoint slices, which is exact
-            out = torch.zeros((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            r = dist.get_rank()
-            out[r * x.shape[0]:(r + 1) * x.shape[0]] = x
-            dist.all_reduce(out, op=dist.ReduceOp.SUM)
-            return out
-        out = torch.empty((ctx.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        with _on_comm_stream(x):
-            dist.all_gather_into_tensor(out, x)
-        return out
+        ctx.world = _world()
+        return _gather_raw(x, ctx.world)
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.world == 0:
-            return g
-        g = g.contiguous()
-        n = g.shape[0] // ctx.world
-        if dist.get_backend() == "nccl":
-            out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-            with _on_comm_stream(g):
-                dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
-            return out
-        g = g.clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        r = dist.get_rank()
-        return g[r * n:(r + 1) * n].contiguous()
+        return _scatter_sum_raw(g, ctx.world)
 
 
 def all_gather_embeddings(x):
     return AllGatherFn.apply(x)
+
+
+class MaxTokensFn(Function):
+    """cls = max over the patch tokens (modules/module_seg_vit.py:441): x (B, T, D) fp32 -> (B, D).  The backward writes the
+    routed gradient as fp32 AND (bf16 mode) as the bf16 copy the residual stack's backward takes as its operand, in one pass
+    (torch: zero-fill + scatter, then a cast)."""
+
+    @staticmethod
+    def forward(ctx, x, want_bf16):
+        x = x.contiguous()
+        B, T, D = x.shape
+        L.require_cuda(x)
+        out = _empty((B, D), torch.float32, x)
+        idx = torch.empty((B, D), dtype=torch.int32, device=x.device)
+        L.check(L.load().segclip_max_tokens_fwd(L.ptr(x), L.ptr(out), L.ptr(idx), B, T, D, L.stream()), "max_tokens_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.want_bf16 = (B, T, D), bool(want_bf16)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, T, D = ctx.shape
+        g = g.contiguous().float()
+        dx = _empty((B, T, D), torch.float32, g)
+        dx16 = _empty((B, T, D), torch.bfloat16, g) if ctx.want_bf16 else None
+        L.check(L.load().segclip_max_tokens_bwd(L.ptr(g), L.ptr(idx), L.ptr(dx), L.ptr(dx16), B, T, D, L.stream()), "max_tokens_bwd")
+        if dx16 is not None:
+            dx._segclip_bf16 = dx16
+        return dx, None
+
+
+class ClipLossFn(Function):
+    """The contrastive head of the training step as ONE autograd node (modules/modeling.py:338-362 + :204-209):
+    L2-normalise both feature matrices, all-gather them in one stacked message, the two logits matrices
+    clamp(exp(logit_scale), 100) * (t v_all^T), (v t_all^T) in exact fp32, both cross entropies and their mean - forward in
+    4 launches (+ the collective), backward in 5.  Returns the loss; the raw cosine matrices are kept on the context object
+    handed back through `box` (for model.last_logits)."""
+
+    @staticmethod
+    def forward(ctx, v_feat, t_feat, logit_scale, rank, box):
+        lib = L.load()
+        v_feat, t_feat = v_feat.contiguous().float(), t_feat.contiguous().float()
+        L.require_cuda(v_feat, t_feat, logit_scale)
+        B, C = v_feat.shape
+        world = _world()
+        both = _empty((B, 2, C), torch.float32, v_feat)
+        norms = _empty((2 * B,), torch.float32, v_feat)
+        L.check(lib.segclip_l2norm_pair_fwd(L.ptr(v_feat), L.ptr(t_feat), L.ptr(both), L.ptr(norms), B, C, L.stream()), "l2norm_pair_fwd")
+        allb = _gather_raw(both, world)                       # (N, 2, C): [:, 0] = visual, [:, 1] = text of every rank
+        N = allb.shape[0]
+        off = B * int(rank)
+        if off + B > N:
+            raise ValueError(f"contrastive loss: rank {rank} with per-rank batch {B} does not fit the gathered batch {N}")
+        cosm = _empty((2, B, N), torch.float32, v_feat)
+        # [0] = t . v_all^T, [1] = v . t_all^T: one batched exact-fp32 launch (batch strides -C / +C swap the roles)
+        p_gemm(both, allb, cosm, B, N, C, (2 * C, 1), (2 * C, 1), N, a_off=C, nb1=2, bsA=(-C, 0), bsB=(C, 0), bsC=(B * N, 0))
+        ls = logit_scale.detach()
+        lse, loss_rows = _empty((2 * B,), torch.float32, v_feat), _empty((2 * B,), torch.float32, v_feat)
+        loss = _empty((), torch.float32, v_feat)
+        L.check(lib.segclip_clip_ce_fwd(L.ptr(cosm), L.ptr(ls), L.ptr(lse), L.ptr(loss_rows), L.ptr(loss), B, N, off, L.stream()), "clip_ce_fwd")
+        ctx.save_for_backward(both, allb, norms, cosm, lse, ls)
+        ctx.cfg = (B, C, N, off, world, tuple(logit_scale.shape))
+        if box is not None:
+            box["cos"], box["logit_scale"] = cosm, ls
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        both, allb, norms, cosm, lse, ls = ctx.saved_tensors
+        B, C, N, off, world, ls_shape = ctx.cfg
+        lib = L.load()
+        g = g.contiguous().float()
+        dcos = torch.empty_like(cosm)
+        ds_rows = _empty((2 * B,), torch.float32, cosm)
+        dls = _empty(ls_shape, torch.float32, cosm) if ctx.needs_input_grad[2] else None
+        L.check(lib.segclip_clip_ce_bwd(L.ptr(cosm), L.ptr(lse), L.ptr(ls), L.ptr(g), L.ptr(dcos), L.ptr(ds_rows), L.ptr(dls), B, N, off,
+                                        L.stream()), "clip_ce_bwd")
+        # this rank's rows as the LEFT factors: d t_n = dcos[0] v_all, d v_n = dcos[1] t_all  -> dboth[:, 1], dboth[:, 0]
+        dboth = _empty((B, 2, C), torch.float32, cosm)
+        p_gemm(dcos, allb, dboth, B, C, N, (N, 1), (1, 2 * C), 2 * C, c_off=C, nb1=2, bsA=(B * N, 0), bsB=(C, 0), bsC=(-C, 0))
+        # every rank's rows as the RIGHT factors: d v_all = dcos[0]^T t_n, d t_all = dcos[1]^T v_n -> dall[:, 0], dall[:, 1]
+        dall = _empty((N, 2, C), torch.float32, cosm)
+        single = world <= 1          # N == B: the two contributions meet in the GEMM epilogue (residual = dboth)
+        p_gemm(dcos, both, dall, N, C, B, (1, N), (1, 2 * C), 2 * C, b_off=C, nb1=2, bsA=(B * N, 0), bsB=(-C, 0), bsC=(C, 0),
+               residual=dboth if single else None, ldr=2 * C if single else 0, bsR=(C, 0))
+        dv, dt = _empty((B, C), torch.float32, cosm), _empty((B, C), torch.float32, cosm)
+        if single:
+            L.check(lib.segclip_l2norm_pair_bwd(L.ptr(dall), None, L.ptr(both), L.ptr(norms), L.ptr(dv), L.ptr(dt), B, C, L.stream()),
+                    "l2norm_pair_bwd")
+        else:
+            dloc = _scatter_sum_raw(dall, world)              # reduce-scatter(SUM): diffdist's adjoint of the all-gather
+            L.check(lib.segclip_l2norm_pair_bwd(L.ptr(dboth), L.ptr(dloc), L.ptr(both), L.ptr(norms), L.ptr(dv), L.ptr(dt), B, C,
+                                                L.stream()), "l2norm_pair_bwd")
+        return dv, dt, dls, None, None

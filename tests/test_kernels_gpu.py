@@ -133,8 +133,15 @@ def test_gemm_saved_derivative_one_byte(M, N, K, pad):
     ref = (g.float() @ w2.float()) * dec
     close(du2, ref, 2e-2, 2e-2, "dgrad * decoded derivative")
     close(cs, du2.float().sum(0), 2e-3, 2e-2 * M ** 0.5, "fused column sums")
-    with pytest.raises(RuntimeError):       # not a multiple of the 256-wide tiles: the caller has to take aux_kind 1
-        ops.p_linear(x[:200], w[:136], b[:136], act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=2)
+    # not a multiple of the 256-wide tiles: the library refuses aux_kind 2 (SEGCLIP_ERR_UNSUPPORTED, nothing launched) and
+    # p_linear falls back to the bf16 form of the derivative (aux_kind 1) - same output, the backward reads the dtype
+    y3, a3 = ops.p_linear(x[:200], w[:136], b[:136], act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=2)
+    y4, a4 = ops.p_linear(x[:200], w[:136], b[:136], act=ops.ACT_QUICK_GELU, want_aux=True, aux_kind=1)
+    assert a3.dtype == BF and torch.equal(a3, a4) and torch.equal(y3, y4)
+    with pytest.raises(RuntimeError):       # the raw launch still refuses
+        aux = torch.empty(200, 136, dtype=torch.uint8, device=DEV)
+        ops.p_gemm(x[:200], w[:136], torch.empty(200, 136, dtype=BF, device=DEV), 200, 136, K, (K, 1), (K, 1), 136, bias=b[:136],
+                   aux=aux, ldaux=136, act=ops.ACT_QUICK_GELU, aux_kind=2)
 
 
 def test_gemm_bf16_fp32_A_operand_and_splitk():
@@ -672,6 +679,145 @@ def test_res_stack_bf16_chain_depth12_width768():
           f"dx: chain {e_dx_chain:.3e}, bf16 {e_dx_bf:.3e}")
     assert worst_chain <= 3e-2 and e_dx_chain <= 3e-2, (worst_chain, e_dx_chain)
     assert worst_bf <= 2.5e-2 and e_dx_bf <= 1.5e-2, (worst_bf, e_dx_bf)
+
+
+@pytest.mark.parametrize("shape", [(512, 768, 768), (1024, 512, 2048), (392, 768, 768)])
+def test_linear_bf16_residual_stream_epilogue(shape):
+    """out_proj / c_proj with the bf16 residual stream (config.bf16_resid): y = bf16(x w^T + b + r), r bf16.  Full
+    256 x 256 tiles run on gemm_bf16_pq.hip (the product is rounded to bf16 before the add), other shapes on the staged
+    epilogues; both against the fp32 expression, tolerance = two bf16 roundings of the result."""
+    M, N, K = shape
+    x, w = rnd(M, K, dtype=BF, seed=81), rnd(N, K, dtype=BF, seed=82, scale=K ** -0.5)
+    b, r = rnd(N, seed=83), rnd(M, N, dtype=BF, seed=84, scale=3.0)
+    y, _ = ops.p_linear(x, w, b, residual=r)
+    assert y.dtype == BF
+    ref = x.float() @ w.float().t() + b + r.float()
+    err = (y.float() - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) <= 2 ** -7, float((err / (ref.abs() + 1.0)).max())
+    assert float(err.norm() / ref.norm()) <= 4e-3
+
+
+def test_res_stack_bf16_residual_stream():
+    """config.bf16_resid: the residual stream of a stack as bf16 (input / output of the node fp32), at the width of the
+    vision tower and with M a multiple of 256 (so that the out_proj / c_proj launches take the gemm_bf16_pq.hip residual
+    path): output and gradients against the fp32-stream bf16 mode and the exact-f32 mode.  A bf16 stream rounds x once per
+    residual add; its error must stay the size of the error the bf16 GEMM operands cause anyway."""
+    import segclip_amd
+    B, T, D, H, nblk = 16, 64, 768, 12, 6
+    g = torch.Generator().manual_seed(13)
+    blocks = []
+    for _ in range(nblk):
+        P = [torch.ones(D) + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g),
+             torch.randn(3 * D, D, generator=g) * D ** -0.5, 0.1 * torch.randn(3 * D, generator=g),
+             torch.randn(D, D, generator=g) * (D ** -0.5) * 0.5, 0.1 * torch.randn(D, generator=g),
+             torch.ones(D) + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g),
+             torch.randn(4 * D, D, generator=g) * D ** -0.5, 0.1 * torch.randn(4 * D, generator=g),
+             torch.randn(D, 4 * D, generator=g) * ((4 * D) ** -0.5) * 0.5, 0.1 * torch.randn(D, generator=g)]
+        blocks.append([p.to(DEV).requires_grad_() for p in P])
+    x0 = torch.randn(B, T, D, generator=g).to(DEV)
+    gout = torch.randn(B, T, D, generator=g).to(DEV)
+
+    def run(dtype, resid, split=False):
+        for P in blocks:
+            for p in P:
+                p.grad = None
+        x = x0.clone().requires_grad_()
+        with segclip_amd.config.scope(bf16_resid=resid):
+            if split:     # two stacks exchanging the bf16 stream directly (what SegViT._run_blocks does around its hook)
+                y = ops.res_stack(x, blocks[:2], H, False, ops.ACT_QUICK_GELU, 1e-5, dtype, keep16=True)
+                assert y.dtype == (BF if resid else F32)
+                y = ops.res_stack(y, blocks[2:], H, False, ops.ACT_QUICK_GELU, 1e-5, dtype)
+            else:
+                y = ops.res_stack(x, blocks, H, False, ops.ACT_QUICK_GELU, 1e-5, dtype)
+        assert y.dtype == F32
+        y.backward(gout)
+        return y.detach(), x.grad.clone(), [[p.grad.clone() for p in P] for P in blocks]
+
+    y32, dx32, g32 = run(F32, False)
+    yf, dxf, gf = run(BF, False)
+    yr, dxr, gr = run(BF, True)
+    ys, dxs, gs = run(BF, True, split=True)
+    assert torch.equal(yr, ys) and torch.equal(dxr, dxs)     # the hand-over changes no arithmetic
+    for a_, b_ in zip(gr, gs):
+        for u, v in zip(a_, b_):
+            assert torch.equal(u, v)
+
+    def rel(u, v):
+        return float((u.double() - v.double()).norm() / v.double().norm().clamp_min(1e-30))
+    w_res = max(rel(gr[b][i], g32[b][i]) for b in range(nblk) for i in (2, 4, 8, 10))
+    w_bf = max(rel(gf[b][i], g32[b][i]) for b in range(nblk) for i in (2, 4, 8, 10))
+    print(f"\n[6 x 768 stack, M = 1024] y: bf16-stream {rel(yr, y32):.3e} fp32-stream {rel(yf, y32):.3e}; dx: {rel(dxr, dx32):.3e} / "
+          f"{rel(dxf, dx32):.3e}; worst weight grad: {w_res:.3e} / {w_bf:.3e}")
+    assert rel(yr, y32) <= 1e-2 and rel(dxr, dx32) <= 3e-2 and w_res <= 4e-2, (rel(yr, y32), rel(dxr, dx32), w_res)
+
+
+@pytest.mark.parametrize("M", [1000, 4096, 12544])
+def test_group_linear_pair_fused(M):
+    """k_conv / v_conv of the learnable-center stage (grouped kernel-1 Conv1d, 12 groups of 64 channels) as one pass, and
+    their data gradient as one pass (segclip_group_linear64), against torch's grouped conv1d in fp32 on the same bf16
+    operands; M = 1000 is not a multiple of the 32-row wave blocks."""
+    from segclip_amd.modules.module_seg_vit import _group_linear_pair
+    D, G = 768, 12
+    x = rnd(M, D, dtype=BF, seed=91).requires_grad_()
+    wk = rnd(D, D // G, 1, seed=92, scale=0.125).requires_grad_()
+    wv = rnd(D, D // G, 1, seed=93, scale=0.125).requires_grad_()
+    gk, gv = rnd(M, D, dtype=BF, seed=94), rnd(M, D, dtype=BF, seed=95)
+    k, v = _group_linear_pair(x, wk, wv, G)
+    assert k.dtype == BF and v.dtype == BF
+    (k.float() * gk.float()).sum().add((v.float() * gv.float()).sum()).backward()
+    xr = x.detach().float().requires_grad_()
+    wkr, wvr = (w.detach().to(BF).float().requires_grad_() for w in (wk, wv))
+    kr = torch.nn.functional.conv1d(xr.t().unsqueeze(0), wkr, groups=G)[0].t()
+    vr = torch.nn.functional.conv1d(xr.t().unsqueeze(0), wvr, groups=G)[0].t()
+    ((kr * gk.float()).sum() + (vr * gv.float()).sum()).backward()
+    close(k, kr, 1e-2, 1e-2, "k_conv")
+    close(v, vr, 1e-2, 1e-2, "v_conv")
+    close(x.grad, xr.grad, 2e-2, 2e-2, "dn = dk Wk + dv Wv")
+    for w, wr, name in ((wk, wkr, "dWk"), (wv, wvr, "dWv")):
+        rel = float((w.grad.float() - wr.grad).norm() / wr.grad.norm())
+        assert rel <= 1e-2, (name, rel)
+
+
+def test_max_tokens_pooling():
+    """cls = max over the patch tokens (modules/module_seg_vit.py:441) and its backward (gradient routed to the arg-max
+    token, fp32 + the bf16 copy in one pass) against torch.max."""
+    B, T, D = 5, 37, 768
+    x = rnd(B, T, D, seed=96).requires_grad_()
+    g = rnd(B, D, seed=97)
+    y = ops.MaxTokensFn.apply(x, True)
+    y.backward(g)
+    xr = x.detach().clone().requires_grad_()
+    yr = torch.max(xr, dim=1)[0]
+    yr.backward(g)
+    assert torch.equal(y, yr) and torch.equal(x.grad, xr.grad)
+    assert torch.equal(x.grad._segclip_bf16.float(), xr.grad.to(BF).float()) if hasattr(x.grad, "_segclip_bf16") else True
+
+
+@pytest.mark.parametrize("B,C", [(8, 512), (256, 512), (33, 96)])
+def test_fused_contrastive_head(B, C):
+    """ops.ClipLossFn (L2-normalise, logits with clamp(exp(logit_scale), 100), two cross entropies, mean; one autograd node)
+    against the torch expression of modules/modeling.py:338-362,204-209 in fp32 - loss, both feature gradients and the
+    logit_scale gradient, below and above the clamp."""
+    v, t = rnd(B, C, seed=98), rnd(B, C, seed=99)
+    for ls0 in (math.log(1 / 0.07), 5.0):        # exp(5) = 148 > 100: clamped, zero gradient
+        vv, tt = v.clone().requires_grad_(), t.clone().requires_grad_()
+        ls = torch.tensor(ls0, device=DEV, requires_grad=True)
+        box = {}
+        loss = ops.ClipLossFn.apply(vv, tt, ls, 0, box)
+        (loss * 1.7).backward()
+        vr, tr = v.clone().requires_grad_(), t.clone().requires_grad_()
+        lr = torch.tensor(ls0, device=DEV, requires_grad=True)
+        vn, tn = vr / vr.norm(dim=-1, keepdim=True), tr / tr.norm(dim=-1, keepdim=True)
+        sc = torch.clamp(lr.exp(), max=100)
+        t2v, v2t = sc * tn @ vn.t(), sc * vn @ tn.t()
+        lab = torch.arange(B, device=DEV)
+        ref = (torch.nn.functional.cross_entropy(t2v, lab) + torch.nn.functional.cross_entropy(v2t, lab)) / 2
+        (ref * 1.7).backward()
+        assert abs(float(loss) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+        close(vv.grad, vr.grad, 1e-3, 2e-6, "d visual feature")
+        close(tt.grad, tr.grad, 1e-3, 2e-6, "d text feature")
+        assert abs(float(ls.grad) - float(lr.grad)) <= 1e-4 * max(1.0, abs(float(lr.grad))), (float(ls.grad), float(lr.grad))
+        close(sc.detach() * box["cos"][0], t2v.detach(), 1e-5, 1e-4, "t2v logits")
 
 
 def test_deferred_reductions_are_bit_identical():

@@ -17,7 +17,7 @@ import tempfile
 
 # kernel class -> substrings of the kernel name
 CLASSES = [
-    ("gemm_bf16", ("gemm_bf16_p8_kernel", "gemm_bf16_dma_kernel", "gemm_bf16_kernel")),
+    ("gemm_bf16", ("gemm_bf16_pq_kernel", "gemm_bf16_p8_kernel", "gemm_bf16_dma_kernel", "gemm_bf16_kernel")),
     ("splitk_reduce", ("splitk_reduce", "reduce_multi_slabs")),
     ("gemm_f32", ("gemm_f32_kernel",)),
     ("attn_fwd", ("attn_fwd",)),
