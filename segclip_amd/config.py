@@ -31,6 +31,9 @@ bf16_resid    : bf16 mode, inside ResStackFn: the residual STREAM itself is bf16
 aux_u8        : bf16 mode: the towers keep QuickGELU'(u) for the backward as ONE BYTE per element where the MLP GEMMs run
                 on full 256 x 256 tiles (q = rint((act' + 0.125) * 204), absolute error <= 0.0025 - about bf16's relative
                 error at the typical magnitude, unbounded RELATIVE error near act' = 0); False keeps it as bf16
+fused_head    : training forward: max-token pooling + ln_post + projection on the pooled row only, and the contrastive head
+                (L2-normalise, all-gather, logits, both cross entropies) as ONE autograd node (ops.ClipLossFn) - ~15 instead
+                of ~90 launches between the last forward GEMM and the first backward GEMM; False: the op-by-op path
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -43,7 +46,7 @@ import types
 import torch
 
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
-                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False,
+                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
                  text_after_blocks=4)
 _tls = threading.local()

@@ -417,9 +417,15 @@ static int choose_splits(const segclip_gemm_desc* d) {
   return s < 1 ? 1 : (int)s;
 }
 
+size_t segclip_gemm_bf16_pq_tail_ws_bytes(const segclip_gemm_desc* d);
 size_t segclip_gemm_bf16_ws_bytes(const segclip_gemm_desc* d) {
   const int s = choose_splits(d);
-  if (s <= 1) return 0;
+  if (s <= 1) {
+    // no split-K: the tail split of gemm_bf16_pq.hip may want a workspace (bf16 / fp32-residual outputs on full 256-tiles)
+    if (want_dma(d) && d->sak == 1 && (d->c_dtype == SEGCLIP_BF16 || (d->c_dtype == SEGCLIP_F32 && d->residual)))
+      return segclip_gemm_bf16_pq_tail_ws_bytes(d);
+    return 0;
+  }
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
   return (size_t)s * nb * d->M * d->N * sizeof(float);
 }

@@ -60,6 +60,11 @@ struct PQArgs {
   int N, K, nbx, ntiles;
   float* Cf;             // PQ_SLAB / PQ_RES32: fp32 output (split-K: slab of K range s at Cf + s * slab_stride), row pitch ldc
   int64_t kper, slab_stride;   // PQ_SLAB: K elements per split (a multiple of 64)
+  // tail split (every mode but PQ_SLAB): the tail_r tiles of the last, partial round of 256 workgroups are cut into tail_S K
+  // ranges; partial accumulators meet in tail_ws [tail_r][tail_S][128 registers][512 lanes] fp32 and the LAST workgroup of a
+  // tile to arrive (tail_cnt[tile], zeroed by the host) sums them in K-range order and runs the epilogue
+  int tail_S, tail_r, nfull;
+  float* tail_ws; int* tail_cnt;
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
@@ -100,6 +105,47 @@ template <int B> __device__ __forceinline__ void acc_read8(float* v) {
       "v_accvgpr_read_b32 %6, a%c14\n\tv_accvgpr_read_b32 %7, a%c15"
       : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7])
       : "i"(B), "i"(B + 1), "i"(B + 2), "i"(B + 3), "i"(B + 4), "i"(B + 5), "i"(B + 6), "i"(B + 7));
+}
+
+template <int B> __device__ __forceinline__ void acc_write8(const float* v) {
+  asm volatile(
+      "v_accvgpr_write_b32 a%c8, %0\n\tv_accvgpr_write_b32 a%c9, %1\n\tv_accvgpr_write_b32 a%c10, %2\n\t"
+      "v_accvgpr_write_b32 a%c11, %3\n\tv_accvgpr_write_b32 a%c12, %4\n\tv_accvgpr_write_b32 a%c13, %5\n\t"
+      "v_accvgpr_write_b32 a%c14, %6\n\tv_accvgpr_write_b32 a%c15, %7"
+      :
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "i"(B), "i"(B + 1), "i"(B + 2),
+        "i"(B + 3), "i"(B + 4), "i"(B + 5), "i"(B + 6), "i"(B + 7)
+      : PQ_AGPRS);
+}
+
+// ---- tail split: exchange of partial accumulators.  Element (register r, thread t) of a partial tile lives at
+// [(r >> 2) * 512 + t] * 4 + (r & 3): a 16-byte store / load per lane and register quad, 1 KiB contiguous per wave.
+template <int C> __device__ __forceinline__ void tail_store_chunk(float* wp, int tid) {
+  float v[8];
+  acc_read8<C * 8>(v);
+  *reinterpret_cast<f32x4*>(wp + ((int64_t)(2 * C) * 512 + tid) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(wp + ((int64_t)(2 * C + 1) * 512 + tid) * 4) = f32x4{v[4], v[5], v[6], v[7]};
+  if constexpr (C + 1 < 16) tail_store_chunk<C + 1>(wp, tid);
+}
+// accumulators = partial[0] + partial[1] + ... + partial[S-1] in THIS order whichever workgroup arrives last (its own
+// partial is taken from its registers): the result does not depend on the arrival order
+template <int C> __device__ __forceinline__ void tail_combine_chunk(const float* wt, int tid, int own, int S) {
+  float t[8], x[8];
+  auto get = [&](int sp, float* o) {
+    if (sp == own) { acc_read8<C * 8>(o); return; }
+    const float* p = wt + (int64_t)sp * (128 * 512);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + ((int64_t)(2 * C) * 512 + tid) * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + ((int64_t)(2 * C + 1) * 512 + tid) * 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  };
+  get(0, t);
+  for (int sp = 1; sp < S; ++sp) {
+    get(sp, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] += x[k];
+  }
+  acc_write8<C * 8>(t);
+  if constexpr (C + 1 < 16) tail_combine_chunk<C + 1>(wt, tid, own, S);
 }
 
 // LDS-DMA pieces, issued from INLINE ASM (hidden from hipcc's waitcnt pass, see gemm_bf16_p8.hip).  Nothing here has a
@@ -425,15 +471,35 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   // PQ_SLAB (split-K): the (K range, tile) units are ordered K-range-major, so that the tiles of ONE K range - which share
   // its operand rows - sit behind one L2
-  const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // tail split: workgroups nfull .. are the K ranges of the tail tiles; the tail_S ranges of a tile share bid & 7 (one XCD)
+  const bool has_tail = MODE != PQ_SLAB && g.tail_S > 1;
+  bool tail = false;
+  int ttile = 0, tsplit = 0;
+  if (has_tail) {
+    if (bid >= g.nfull) {
+      const int j = bid - g.nfull, qq = j >> 3;
+      ttile = (qq / g.tail_S) * 8 + (j & 7);
+      tsplit = qq % g.tail_S;
+      if (ttile >= g.tail_r) return;
+      tail = true;
+      unit = g.nfull + ttile;
+    } else {
+      const int qf = g.nfull >> 3;               // nfull is a multiple of 256
+      unit = xcd * qf + (bid >> 3);
+    }
+  }
   const int ksplit = MODE == PQ_SLAB ? unit / g.ntiles : 0;
   const int tile = MODE == PQ_SLAB ? unit - ksplit * g.ntiles : unit;
   const int tcol = tile % g.nbx, trow = tile / g.nbx;
   const int64_t m0 = (int64_t)trow * BT, n0 = (int64_t)tcol * BT;
-  const int64_t kb = MODE == PQ_SLAB ? (int64_t)ksplit * g.kper : 0;
+  const int nkt = g.K / BK;
+  const int tk0 = tail ? tsplit * nkt / g.tail_S : 0;
+  const int64_t kb = MODE == PQ_SLAB ? (int64_t)ksplit * g.kper : (int64_t)tk0 * BK;
   const char* baseA = reinterpret_cast<const char*>(A_KS ? g.A + m0 + kb * g.lda : g.A + m0 * g.lda + kb);
   const char* baseB = reinterpret_cast<const char*>(B_KS ? g.B + n0 + kb * g.ldb : g.B + n0 * g.ldb + kb);
-  const int nk = MODE == PQ_SLAB ? (int)((g.K - kb < g.kper ? g.K - kb : g.kper) / BK) : g.K / BK;
+  const int nk = MODE == PQ_SLAB ? (int)((g.K - kb < g.kper ? g.K - kb : g.kper) / BK)
+                                 : (tail ? (tsplit + 1) * nkt / g.tail_S - tk0 : nkt);
   const int64_t stepA = A_KS ? (int64_t)BK * g.lda * 2 : BK * 2;
   const int64_t stepB = B_KS ? (int64_t)BK * g.ldb * 2 : BK * 2;
   const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void*)smem);
@@ -588,6 +654,23 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   if (wr == 0) PQ_BAR();     // group 0 catches up: every wave is done with the operand ring, the VM queue is empty
 
   if (g.abl & 2) return;
+  if (has_tail && tail) {
+    // partial tile -> workspace; the last workgroup of the tile to arrive sums the tail_S partials and goes on to the epilogue
+    asm volatile("" : "+v"(tid));
+    float* const wt = g.tail_ws + (int64_t)ttile * g.tail_S * (128 * 512);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // last MFMA -> v_accvgpr_read
+    tail_store_chunk<0>(wt + (int64_t)tsplit * (128 * 512), tid);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // EVERY wave: its partial is visible device-wide before it arrives
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(smem);        // the operand ring is free by now
+    if (tid == 0) *flag = __hip_atomic_fetch_add(g.tail_cnt + ttile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrived = *reinterpret_cast<volatile int*>(flag);
+    __syncthreads();
+    if (arrived != g.tail_S - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    tail_combine_chunk<0>(wt, tid, tsplit, g.tail_S);
+  }
   // ---- output
   asm volatile("" : "+v"(lane));   // lane-dependent epilogue addresses are derived here, not kept live across the K loop
   const int li = lane & 31, lk = lane >> 5;
@@ -698,6 +781,52 @@ void segclip_pq_launch_w(int mode, dim3 grid, hipStream_t stream, const void* ar
 #endif
 
 #if PQ_PART == 2
+// Tail split plan of a launch with `ntiles` full tiles and nkt K-tiles: r = tiles of the last partial round of 256 workgroups,
+// S = K ranges per tail tile (0 = no tail split).  The idea: 588 tiles (N = 768 at M = 50176) are 2.3 rounds of 256 CUs and
+// take the time of 3; with the 76 tail tiles cut into 3 K ranges the third round would cost a third of the K loop + the
+// exchange.  MEASURED (MI355X, round 4, tools/bench_pq.py with SEGCLIP_PQ_TAIL=0/2/3; results equal to the unsplit kernel up
+// to the order of the partial sums, deterministic): SLOWER - K = 3072: 220 -> 248 us (S = 2) / 271 us (S = 3), K = 2304:
+// 162 -> 203 / 229 us, the training step 42.1 -> 43.5 / 44.3 ms.  The exchange needs an agent-scope release (buffer_wbl2 sc1:
+// the XCD's L2 writes back every dirty output line) per arriving workgroup and an acquire (buffer_inv sc1) in the last one,
+// whose 2 x 256 KiB of partials then arrive at one CU's load rate.  OFF by default (SEGCLIP_PQ_TAIL=2..4 enables it for A/B).
+static int pq_tail_plan(int64_t ntiles, int64_t nkt, int* r_out) {
+  static const int env = [] { const char* e = getenv("SEGCLIP_PQ_TAIL"); return e ? atoi(e) : 0; }();
+  static const int min_nkt = [] { const char* e = getenv("SEGCLIP_PQ_TAIL_MINK"); return e ? atoi(e) : 24; }();
+  *r_out = 0;
+  if (!env || ntiles <= 256) return 0;
+  const int r = (int)(ntiles % 256);
+  if (r == 0 || r > 128) return 0;
+  int S = 256 / r;
+  if (S > 4) S = 4;
+  if (env > 1 && S > env) S = env;      // SEGCLIP_PQ_TAIL = 2..4 caps the number of ranges
+  if (S < 2 || nkt < min_nkt || nkt / S < 4) return 0;
+  *r_out = r;
+  return S;
+}
+static size_t pq_tail_ws_bytes(int r, int S) { return 4096 + (size_t)r * S * 128 * 512 * sizeof(float); }
+// workspace the tail split of this descriptor wants (0 = none): counters (4 KiB) + partial tiles
+size_t segclip_gemm_bf16_pq_tail_ws_bytes(const segclip_gemm_desc* d) {
+  if (d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16 || d->sak != 1) return 0;
+  if (d->M % BT != 0 || d->N % BT != 0 || d->K % BK != 0 || d->K < BK) return 0;
+  if ((d->nb1 > 1) || (d->nb2 > 1)) return 0;
+  int r = 0;
+  const int S = pq_tail_plan((d->M / BT) * (d->N / BT), d->K / BK, &r);
+  return S ? pq_tail_ws_bytes(r, S) : 0;
+}
+// fills the tail-split fields of g when the caller's workspace allows it; zeroes the arrival counters on the stream
+static bool pq_tail_setup(PQArgs& g, const segclip_gemm_desc* d, hipStream_t stream, unsigned* nwg) {
+  int r = 0;
+  const int S = pq_tail_plan(g.ntiles, g.K / BK, &r);
+  *nwg = (unsigned)g.ntiles;
+  if (!S || d->ws == nullptr || (size_t)d->ws_bytes < pq_tail_ws_bytes(r, S) || (reinterpret_cast<uintptr_t>(d->ws) & 15) != 0) return true;
+  if (hipMemsetAsync(d->ws, 0, 4096, stream) != hipSuccess) return false;
+  g.tail_S = S; g.tail_r = r; g.nfull = g.ntiles - r;
+  g.tail_cnt = reinterpret_cast<int*>(d->ws);
+  g.tail_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ws) + 4096);
+  *nwg = (unsigned)(g.nfull + 8 * S * ((r + 7) / 8));
+  return true;
+}
+
 void segclip_pq_launch_f(int, dim3, hipStream_t, const void*);
 void segclip_pq_launch_k(int, dim3, hipStream_t, const void*);
 void segclip_pq_launch_w(int, dim3, hipStream_t, const void*);
@@ -747,7 +876,9 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     g.lda = d->sam; g.ldb = d->sbn; g.Cf = reinterpret_cast<float*>(d->C); g.ldc = d->ldc;
     g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
     { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
-    segclip_pq_launch_f(PQ_RES32, dim3((unsigned)g.ntiles), stream, &g);
+    unsigned nwg = 0;
+    if (!pq_tail_setup(g, d, stream, &nwg)) return false;
+    segclip_pq_launch_f(PQ_RES32, dim3(nwg), stream, &g);
     return true;
   }
   if (d->c_dtype != SEGCLIP_BF16) return false;
@@ -783,7 +914,9 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = mode == PQ_RES ? d->ldr : d->ldaux; g.ldaux = d->ldaux;
   g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
   { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
-  (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3((unsigned)g.ntiles), stream, &g);
+  unsigned nwg = 0;
+  if (!pq_tail_setup(g, d, stream, &nwg)) return false;
+  (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3(nwg), stream, &g);
   return true;
 }
 #endif  // PQ_PART == 2

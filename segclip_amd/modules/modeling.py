@@ -135,6 +135,13 @@ class SegCLIP(SegCLIPPreTrainedModel):
         from .. import streams
         return streams.side_stream("text")
 
+    def _visual_feature(self, image, image_frame):
+        """(pooled visual feature (B, 1, embed) or (B, embed), mid_states) of the training forward"""
+        if config.fused_head:
+            return self.clip.encode_image_pooled(image)
+        visual_output, _hidden, mid_states = self.get_visual_output(image, shaped=True, image_frame=image_frame, return_hidden=True)
+        return visual_output, mid_states
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, token_type_ids, attention_mask, image, image_seg=None):
         """modules/modeling.py:174-256.  token_type_ids / attention_mask are accepted and ignored on this
@@ -182,7 +189,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
                 enqueue_text()
             pending = None
             try:
-                visual_output, mid_states = self.clip.encode_image_pooled(image)
+                visual_output, mid_states = self._visual_feature(image, image_frame)
                 pending = config.take_stack_hook()      # a vision tower without a fused stack never ran the hook
             finally:
                 config.take_stack_hook()                # never leave a stale hook behind an exception
@@ -193,13 +200,21 @@ class SegCLIP(SegCLIPPreTrainedModel):
             sequence_output.record_stream(main)
         else:
             sequence_output = self.clip.encode_text_eot(input_ids).unsqueeze(1)
-            visual_output, mid_states = self.clip.encode_image_pooled(image)
+            visual_output, mid_states = self._visual_feature(image, image_frame)
         self.last_mid_states = _detached(mid_states)
-        # contrastive head (modules/modeling.py:196-210,338-362) as one autograd node: L2-normalise, one stacked all-gather,
-        # both logits matrices in exact fp32, both cross entropies, their mean
         self._last_head = {}
-        loss = ops.ClipLossFn.apply(visual_output.float().view(b, -1), sequence_output.squeeze(1).float(), self.clip.logit_scale,
-                                    int(getattr(self.task_config, "rank", 0)), self._last_head)
+        if config.fused_head:
+            # contrastive head (modules/modeling.py:196-210,338-362) as one autograd node: L2-normalise, one stacked
+            # all-gather, both logits matrices in exact fp32, both cross entropies, their mean
+            loss = ops.ClipLossFn.apply(visual_output.float().view(b, -1), sequence_output.squeeze(1).float(),
+                                        self.clip.logit_scale, int(getattr(self.task_config, "rank", 0)), self._last_head)
+        else:
+            sim_matrix_t2v, sim_matrix_v2t = self._loose_similarity(sequence_output, visual_output)
+            offset = sequence_output.size(0) * int(getattr(self.task_config, "rank", 0))
+            sim_loss1 = ops.CrossEntropyFn.apply(sim_matrix_t2v, offset)
+            sim_loss2 = ops.CrossEntropyFn.apply(sim_matrix_v2t, offset)
+            loss = (sim_loss1 + sim_loss2) / 2.
+            self._last_head["logits"] = (sim_matrix_t2v.detach(), sim_matrix_v2t.detach())
         self.last_losses = {"contrastive": loss.detach()}
         if self.use_seglabel:
             image_seg_ = torch.as_tensor(image_seg)[:, 0].reshape(b, -1)
@@ -241,6 +256,8 @@ class SegCLIP(SegCLIPPreTrainedModel):
         h = getattr(self, "_last_head", None)
         if not h:
             return None
+        if "logits" in h:
+            return h["logits"]
         s = torch.clamp(h["logit_scale"].exp(), max=100)
         return s * h["cos"][0], s * h["cos"][1]
 
