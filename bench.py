@@ -352,6 +352,8 @@ def main():
         segclip_amd.config.bf16_resid = a.resid == "bf16"
     if os.environ.get("SEGCLIP_FUSED_HEAD", "1") == "0":     # A/B switch of the fused pooled-feature + contrastive head
         segclip_amd.config.fused_head = False
+    if os.environ.get("SEGCLIP_REDUCE_SIDE", "0") == "1":    # A/B switch: trailing reductions on a side stream (measured slower)
+        segclip_amd.config.reduce_side = True
     if a.text_after_blocks >= 0:
         segclip_amd.config.text_after_blocks = a.text_after_blocks
     if os.environ.get("SEGCLIP_OVERLAP_WGRAD", "0") == "1":   # experiment switch: weight gradients on a second stream

@@ -34,6 +34,12 @@ aux_u8        : bf16 mode: the towers keep QuickGELU'(u) for the backward as ONE
 fused_head    : training forward: max-token pooling + ln_post + projection on the pooled row only, and the contrastive head
                 (L2-normalise, all-gather, logits, both cross entropies) as ONE autograd node (ops.ClipLossFn) - ~15 instead
                 of ~90 launches between the last forward GEMM and the first backward GEMM; False: the op-by-op path
+reduce_side   : inside ResStackFn's backward the blocks' trailing reductions (split-K combines of the weight gradients, the
+                LayerNorm / bias column sums - HBM-bound, off the data-gradient chain) run on a side stream beside the next
+                block's GEMMs and are joined once per stack (not with GradSync's bucket slots).  MEASURED SLOWER and off: 51.9 vs
+                41.9 ms per step - with two more active streams the runtime maps the text tower's stream onto the main
+                stream's hardware queue and the towers run one after the other (the effect DESIGN.md 6 "hardware queues"
+                describes)
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -46,7 +52,7 @@ import types
 import torch
 
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
-                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True,
+                 trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
                  text_after_blocks=4)
 _tls = threading.local()

@@ -85,13 +85,30 @@ class ReduceQueue:
         self.keep.append(part)
         self.keep.extend(o for o in outs if o is not None)
 
-    def flush(self):
+    def flush(self, side=None):
+        """side: a HIP stream the reductions are enqueued on instead of the current one (they are HBM-bound and feed nothing
+        in the data-gradient chain: beside the next block's GEMMs they cost almost nothing); the caller joins it before
+        anything reads the reduced gradients."""
         lib = L.load()
-        for kind, ents in ((L.REDUCE_SLABS, self.slabs), (L.REDUCE_ROWS, self.rows)):
-            for i in range(0, len(ents), L.REDUCE_MAX):
-                chunk = ents[i:i + L.REDUCE_MAX]
-                arr = (L.ReduceEntry * len(chunk))(*chunk)
-                L.check(lib.segclip_reduce_multi(arr, len(chunk), kind, L.stream()), "reduce_multi")
+        if not self.slabs and not self.rows:
+            return
+        main = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(main)               # the partials were produced on the current stream
+
+        def launch():
+            for kind, ents in ((L.REDUCE_SLABS, self.slabs), (L.REDUCE_ROWS, self.rows)):
+                for i in range(0, len(ents), L.REDUCE_MAX):
+                    chunk = ents[i:i + L.REDUCE_MAX]
+                    arr = (L.ReduceEntry * len(chunk))(*chunk)
+                    L.check(lib.segclip_reduce_multi(arr, len(chunk), kind, L.stream()), "reduce_multi")
+        if side is None:
+            launch()
+        else:
+            with torch.cuda.stream(side):
+                launch()
+            for t in self.keep:                  # workspaces / outputs stay allocated until the side stream has used them
+                t.record_stream(side)
         self.slabs, self.rows, self.keep = [], [], []
 
 
@@ -407,6 +424,12 @@ def _wgrad_stream():
     return streams.side_stream("wgrad")
 
 
+def _reduce_stream():
+    """side stream for a tower's trailing reductions (one per tower: keyed by the stream the tower's backward runs on)"""
+    from . import streams
+    return streams.side_stream("reduce:%x" % torch.cuda.current_stream().cuda_stream)
+
+
 # config.overlap_wgrad experiments (read once): SEGCLIP_WGRAD_JOIN=stack joins the weight-gradient stream once per
 # ResStackFn backward instead of once per block (the tensors it reads are kept alive until then); the stream's priority
 # comes from SEGCLIP_WGRAD_PRIO (segclip_amd/streams.py)
@@ -664,7 +687,7 @@ def _aux_kind(act_dtype, act, M=0, N=0):
     return 0
 
 
-def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None):
+def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None, reduce_side=None):
     """Hand-scheduled backward of one block.  g: fp32 (M, D) gradient of the block output or None; g16: its bf16 copy or
     None.  need[i]: gradient wanted for forward input i (0 = x, 1..12 = the parameters in forward order).
     chain=False: fp32 residual gradient in and out (plus the bf16 copy the LayerNorm backward emits for free).
@@ -737,7 +760,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
                  outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
                        _slot_out(s_bo, (D,)) if need[6] else None), defer=rq)
     if rq is not None:
-        rq.flush()
+        rq.flush(reduce_side)
     dln1w, dln1b = r[1], r[2]
     dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
     if side is not None:
@@ -850,6 +873,11 @@ class ResStackFn(Function):
         need_all = ctx.needs_input_grad
         out = [None] * (nblk * 12)
         keep = [] if (ctx.overlap_wgrad and _WGRAD_JOIN_STACK) else None
+        # config.reduce_side: the blocks' trailing reductions (split-K combines, LayerNorm / bias column sums) go to a side
+        # stream and are joined once, at the end of the stack - not with GradSync slots (their bucket exchange is ordered
+        # against the stream that PRODUCED a gradient, which must then be this one)
+        from . import config as _cfg
+        rside = _reduce_stream() if (_cfg.reduce_side and not ctx.overlap_wgrad and all(s is None for s in ctx.slots)) else None
         for b in reversed(range(nblk)):
             P = ctx.params[b * 12:(b + 1) * 12]
             sl = ctx.slots[b * 12:(b + 1) * 12]
@@ -857,7 +885,7 @@ class ResStackFn(Function):
             gslots = (sl[2], sl[4], sl[8], sl[10])
             vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
             cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
-                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep)
+                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep, rside)
             for i, (p, gr, slot) in enumerate(zip(P, grads, sl)):
                 if gr is None:
                     continue
@@ -871,6 +899,8 @@ class ResStackFn(Function):
         if keep is not None:
             torch.cuda.current_stream().wait_stream(_wgrad_stream())
             keep.clear()
+        if rside is not None:
+            torch.cuda.current_stream().wait_stream(rside)     # the parameter gradients are complete when the node returns
         if ctx.chain and ctx.in_dtype == torch.bfloat16:
             dx = cur16                       # the producer is a stack with a bf16 output: no cast, no side copy
         elif ctx.chain:
