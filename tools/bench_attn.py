@@ -4,7 +4,8 @@ import torch
 from segclip_amd import ops
 from tools.bench_gemm import timeit
 dev, BF = "cuda", torch.bfloat16
-for (B, T, H, causal) in [(256, 196, 12, False), (256, 77, 8, True)]:
+SHAPES = [(256, 196, 12, False), (256, 77, 8, True)]
+for (B, T, H, causal) in SHAPES:
     hd, D = 64, H * 64
     qkv = torch.randn(B * T, 3 * D, device=dev).to(BF)
     o = torch.empty(B * T, D, dtype=BF, device=dev)
@@ -18,3 +19,18 @@ for (B, T, H, causal) in [(256, 196, 12, False), (256, 77, 8, True)]:
     tb = timeit(lambda: ops.p_attn_bwd(desc(), stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D))
     fl = 4.0 * B * H * T * T * hd * (0.5 if causal else 1.0)
     print(f"B{B} T{T} H{H} causal={causal}: fwd {tf*1e6:7.1f} us ({fl/tf/1e12:6.1f} TF/s)  bwd {tb*1e6:7.1f} us ({2.5*fl/tb/1e12:6.1f} TF/s)")
+# same-node yardstick, AFTER all rows above (its allocations and clocks must not sit between them): torch's fused attention
+# (scaled_dot_product_attention, bf16) on the same shapes
+import torch.nn.functional as F
+for (B, T, H, causal) in SHAPES:
+    hd = 64
+    fl = 4.0 * B * H * T * T * hd * (0.5 if causal else 1.0)
+    q, k, v = (torch.randn(B, H, T, hd, device=dev, dtype=BF, requires_grad=True) for _ in range(3))
+    go = torch.randn(B, H, T, hd, device=dev, dtype=BF)
+    try:
+        ts = timeit(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=causal))
+        oo = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
+        tsb = timeit(lambda: torch.autograd.grad(oo, (q, k, v), go, retain_graph=True))
+        print(f"[torch SDPA] B{B} T{T} H{H} causal={causal}: fwd {ts*1e6:7.1f} us ({fl/ts/1e12:6.1f} TF/s)  bwd {tsb*1e6:7.1f} us ({2.5*fl/tsb/1e12:6.1f} TF/s)")
+    except Exception as e:
+        print(f"[torch SDPA] not available here: {type(e).__name__}: {str(e)[:120]}")

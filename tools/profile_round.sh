@@ -14,6 +14,7 @@ rm -rf $OUT/rl/trace $OUT/rl/pmc_*
 b() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "$name: $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$name.json) $(grep -o '"value": [0-9.]*' $OUT/bench_$name.json | head -1)"; }
 b gb2048 --no-cpu-baseline --no-traffic --global-batch 2048 --steps 5 --warmup 2
 b full_loss --no-cpu-baseline --no-traffic --full-loss
+b resid_bf16 --no-cpu-baseline --no-roofline --resid bf16
 b dist --no-cpu-baseline --no-roofline --force-dist
 b dist_bf16wire --no-cpu-baseline --no-roofline --force-dist --wire bf16
 b vitl14 --no-cpu-baseline --no-traffic --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
@@ -24,6 +25,9 @@ timeout 300 python tools/bench_gemm.py 2>&1 | grep -v "$F" > $OUT/gemm_shapes.tx
 timeout 300 python tools/bench_gemm.py 19712 text 2>&1 | grep -v "$F" >> $OUT/gemm_shapes.txt
 timeout 300 python tools/bench_epi.py 2>&1 | grep -v "$F" > $OUT/gemm_epilogues.txt
 timeout 200 python tools/bench_attn.py 2>&1 | grep -v "$F" > $OUT/attn.txt
+timeout 300 python tools/bench_pq.py 2>&1 | grep -v "$F" | grep -v "^check" > $OUT/gemm_pq.txt
+timeout 300 python tools/bench_pq.py 19712 2>&1 | grep -v "$F" | grep -v "^check" >> $OUT/gemm_pq.txt
+timeout 600 python tools/bench_eager.py --classes 2>/dev/null | grep "^{" > $OUT/eager_ab.json
 for spec in "50176 768 3072 nt" "50176 3072 768 dgrad" "50176 2304 768 wgrad"; do
   set -- $spec
   timeout 600 bash tools/pmc_gemm.sh $1 $2 $3 $4 $OUT/pmc_gemm_$4 > $OUT/pmc_gemm_$4.txt 2>&1

@@ -23,10 +23,12 @@ hdr = ("# Kernel table of the rocprofv3 child that bench.py's roofline block is 
        "#   SEGCLIP_BENCH_PROFILE_DIR=... python bench.py --steps 20 --warmup 5  ->  profiles/%s_bench_line.json, same run).\n"
        "# 6 model passes of the child are in the trace; ms/step = total_ms / 6.  at::cuda::spin_kernel = the stream-overlap probe\n"
        "# of segclip_amd/streams.py (once per process, not step work).  Step time of the (unprofiled) parent: %.3f ms.\n"
-       "# gemm_bf16_p8_kernel<A_KS,B_KS>: <0,0> forward NT, <0,1> data gradient, <1,1> weight gradient (split-K).\n") % (tag, tag, line["ms_per_step"])
+       "# gemm_bf16_pq_kernel<A_KS,B_KS,MODE>: <0,0,*> forward (0 plain, 2 QuickGELU + one-byte derivative, 5 + fp32 residual),\n"
+       "#   <0,1,*> data gradient (0 plain, 3 x saved derivative), <1,1,4> weight gradient (split-K slabs).\n") % (tag, tag, line["ms_per_step"])
 open(P + "bench_kernel_stats.txt", "w").write(hdr + open(R + "kernel_stats.txt").read())
 cfg = {}
 for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base on one GPU)"), ("full_loss", "--full-loss (BASELINE configs[3])"),
+                ("resid_bf16", "--resid bf16: bf16 residual stream between the blocks of a tower (config.bf16_resid, opt-in)"),
                 ("dist", "--force-dist: N>1 code path (RCCL group, GradSync fp32 wire) on one rank"), ("dist_bf16wire", "--force-dist --wire bf16"),
                 ("vitl14", "--spec vitl14_336 --batch 128 --attn-fp8 off (BASELINE configs[4], bf16 attention)"),
                 ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("b64", "--batch 64"), ("b128", "--batch 128"), ("b512", "--batch 512")):
@@ -55,7 +57,7 @@ for mode, (desc, M, N, K) in shapes.items():
             m = re.match(r"\s+(\S+)\s+\d+\s+\(per launch\s+(\d+)", l)
             if m and cur:
                 g[cur][m.group(1)] = float(m.group(2))
-    k = g.get("gemm_bf16_p8_kernel")
+    k = g.get("gemm_bf16_pq_kernel") or g.get("gemm_bf16_p8_kernel")
     if k:
         ns = k["_ns_SQ_WAVE_CYCLES"]; cyc = k["GRBM_GUI_ACTIVE"] / 8
         fl = 2.0 * M * N * K
@@ -70,9 +72,15 @@ open(P + "attn_pmc.txt", "w").write("# rocprofv3 --pmc passes on the attention k
                                    "# attn_bwd_sp_bf16_kernel = the single-pass backward (attention_sp.inc)\n" + open(R + "pmc_attn.txt").read())
 for a, h in (("gemm_shapes.txt", "# GEMM rates per shape (tools/bench_gemm.py, HIP events, 10 launches each) next to torch.matmul (hipBLASLt) on the same MI355X.\n"),
              ("gemm_epilogues.txt", "# Fused-epilogue variants of one residual block's GEMMs against the plain kernel (tools/bench_epi.py, M = 50176, D = 768)\n"),
+             ("gemm_pq.txt", "# gemm_bf16_pq.hip against the 8-phase kernel gemm_bf16_p8.hip per shape and mode, interleaved rounds (tools/bench_pq.py), M = 50176 (vision) and 19712 (text)\n"),
              ("hbm_kernels.txt", "# HBM-bound kernels against 8 TB/s (tools/bench_hbm.py)\n"),
              ("attn.txt", "# attention kernels in isolation (tools/bench_attn.py): T=196 vision (single-pass backward), T=77 causal text\n"),
              ("stream_gaps.txt", "# tools/stream_gaps.py on the kernel trace of the bench child (profiled run: the host is slower than in the timed run)\n")):
     if os.path.exists(R + a):
         open(P + a, "w").write(h + open(R + a).read())
+if os.path.exists(R + "eager_ab.json"):
+    e = last_json(R + "eager_ab.json")
+    e["segclip_amd_same_run"] = {"pairs_per_s": line["value"], "ms_per_step": line["ms_per_step"]}
+    e["speedup_vs_eager"] = round(line["value"] / e["pairs_per_s"], 2)
+    json.dump(e, open(P + "eager_ab.json", "w"), indent=1)
 print("wrote", P + "*")
