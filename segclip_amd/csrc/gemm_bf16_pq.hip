@@ -68,6 +68,7 @@ struct PQArgs {
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) const char lds_cchar;
@@ -270,12 +271,23 @@ __device__ __forceinline__ void pq_block(const PQArgs& g, lds_char* sm, const f3
       for (int k = 0; k < 4; ++k) w[k] = v[gq * 4 + k] + bias[gq][k];
     }
     if constexpr (MODE == PQ_ACT8) {
+      // QuickGELU and its derivative on PAIRS (v_pk_mul / v_pk_add / v_pk_fma_f32: the same IEEE operations as the scalar
+      // form of sigmoid1702 / act_with_side, two elements per instruction; exp2 and rcp stay scalar): the epilogue of the
+      // c_fc forward is VALU work in a phase the matrix pipe idles in
       uint32_t q = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float sd;
-        w[k] = act_with_side(SEGCLIP_ACT_QUICK_GELU, 1, w[k], &sd);
-        q = __builtin_amdgcn_cvt_pk_u8_f32((sd + AUX8_OFF) * AUX8_SCALE, k, q);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const v2f x = v2f{w[2 * k2], w[2 * k2 + 1]};
+        const v2f e = x * v2f{-2.4554669595930157f, -2.4554669595930157f};
+        const v2f d = v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + v2f{1.0f, 1.0f};
+        const v2f sg = v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const v2f t = (x * v2f{1.702f, 1.702f}) * (v2f{1.0f, 1.0f} - sg) + v2f{1.0f, 1.0f};
+        const v2f sd = sg * t;                                   // act'(u) = s (1 + 1.702 u (1 - s))
+        const v2f y = x * sg;
+        const v2f qf = sd * v2f{AUX8_SCALE, AUX8_SCALE} + v2f{AUX8_OFF * AUX8_SCALE, AUX8_OFF * AUX8_SCALE};
+        w[2 * k2] = y[0]; w[2 * k2 + 1] = y[1];
+        q = __builtin_amdgcn_cvt_pk_u8_f32(qf[0], 2 * k2, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(qf[1], 2 * k2 + 1, q);
       }
       *reinterpret_cast<lds_u32*>(sm + AO_OFF + J * 16384 + row128 + (c8 << 4) +
                                   ((((gq & 1) * 2 + lk) ^ ((li >> 3) & 3)) << 2)) = q;

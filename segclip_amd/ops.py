@@ -755,7 +755,16 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
     dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
     dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)), defer=rq)) if need[3] else None
-    dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv, out=_slot_out(s_bqkv, (3 * D,)))) if need[4] else None
+    dbqkv = None
+    if need[4]:
+        bq_out = _slot_out(s_bqkv, (3 * D,))
+        if part is not None and rq is not None and (bq_out is None or bq_out.data_ptr() % 16 == 0):
+            # in_proj bias gradient = token sums of dQ|dK|dV, left per sample by the attention backward: its B partial rows
+            # join the block's ONE row-reduction launch (was: a column-sum launch + its reduction per block)
+            dbqkv = bq_out if bq_out is not None else _empty((3 * D,), torch.float32, x2)
+            rq.add_rows(part, B, 3 * D, 3 * D, (dbqkv,), 3 * D)
+        else:
+            dbqkv = on_side(lambda: p_colsum(part if part is not None else dqkv, out=bq_out))
     r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
                  outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
                        _slot_out(s_bo, (D,)) if need[6] else None), defer=rq)
