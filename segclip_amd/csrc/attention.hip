@@ -751,7 +751,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     a.scale = d->scale; a.causal = d->causal;
     a.colsum_part = (float*)d->colsum_part;
     a.klen = (const int*)d->klen;
-    static const int abl_env = [] { const char* e = getenv("SEGCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    static const int abl_env = segclip_ablation_env("SEGCLIP_ATTN_ABL");
     a.abl = abl_env;
     a.nitems = (int)(d->B * d->H);
     if (d->Tq > TMAX || d->Tk > TMAX) {

@@ -99,3 +99,16 @@ __device__ __forceinline__ float apply_act_grad(int act, float x) {
 }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Timing ablations that produce GARBAGE results (SEGCLIP_ATTN_ABL, SEGCLIP_P8_EPI_ABL, SEGCLIP_P8_ABL, SEGCLIP_PQ_ABL) exist only in
+// libraries built with `build.sh -DSEGCLIP_EXPERIMENTS`; a production build ignores those environment variables.
+#include <stdlib.h>
+static inline int segclip_ablation_env(const char* name) {
+#ifdef SEGCLIP_EXPERIMENTS
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+#else
+  (void)name;
+  return 0;
+#endif
+}

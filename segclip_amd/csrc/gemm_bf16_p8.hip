@@ -540,7 +540,7 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
   static const int touch = [] { const char* e = getenv("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
   static const int stagger = [] { const char* e = getenv("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 2000; }();   // unit cap in cycles; 0 = off.  In the step (two runs each): 5000: 43.74 ms, 2000: 43.50, 1000: 43.47, 0: 43.47, 12000: 43.98
-  static const int epi_abl = [] { const char* e = getenv("SEGCLIP_P8_EPI_ABL"); return e ? atoi(e) : 0; }();
+  static const int epi_abl = segclip_ablation_env("SEGCLIP_P8_EPI_ABL");
   g.abl = epi_abl;
   g.touch = (touch ? 1 : 0) | (stagger > 0 ? 0 : 2) | (stagger << 2);   // bit 0: side-tile touch experiment, bit 1: no first-round stagger
   g.nbx = (int)cdiv(d->N, BT);
@@ -568,7 +568,7 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   }
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)splits, (unsigned)nb);
 #ifdef SEGCLIP_P8_ABLATIONS
-  static const int abl = [] { const char* e = getenv("SEGCLIP_P8_ABL"); return e ? atoi(e) : 0; }();
+  static const int abl = segclip_ablation_env("SEGCLIP_P8_ABL");
   if (!a_ks && !b_ks && abl >= 1 && abl <= 4) {
     (abl == 1 ? segclip_p8_launch_abl1 : abl == 2 ? segclip_p8_launch_abl2 : abl == 3 ? segclip_p8_launch_abl3
                                                                              : segclip_p8_launch_abl4)(grid, stream, &g);

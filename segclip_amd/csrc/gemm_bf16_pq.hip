@@ -869,7 +869,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     if (splits > 1) { g.Cf = a.slab; g.ldc = d->N; g.kper = a.kper; g.slab_stride = d->M * d->N; }
     else { g.Cf = reinterpret_cast<float*>(d->C); g.ldc = d->ldc; g.kper = d->K; g.slab_stride = 0; }
     if (256 * g.ldc * 4 >= (int64_t)1 << 31) return false;
-    { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
+    g.abl = mode_env == 2 ? segclip_ablation_env("SEGCLIP_PQ_ABL") : 0;
     segclip_pq_launch_w(PQ_SLAB, dim3((unsigned)(g.ntiles * splits)), stream, &g);
     return true;
   }
@@ -887,7 +887,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     g.bias = d->bias; g.side = d->residual; g.lds = d->ldr;
     g.lda = d->sam; g.ldb = d->sbn; g.Cf = reinterpret_cast<float*>(d->C); g.ldc = d->ldc;
     g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
-    { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
+    g.abl = mode_env == 2 ? segclip_ablation_env("SEGCLIP_PQ_ABL") : 0;
     unsigned nwg = 0;
     if (!pq_tail_setup(g, d, stream, &nwg)) return false;
     segclip_pq_launch_f(PQ_RES32, dim3(nwg), stream, &g);
@@ -925,7 +925,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   g.colsum_part = a.colsum_part;
   g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = mode == PQ_RES ? d->ldr : d->ldaux; g.ldaux = d->ldaux;
   g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
-  { const char* e = mode_env == 2 ? getenv("SEGCLIP_PQ_ABL") : nullptr; g.abl = e ? atoi(e) : 0; }
+  g.abl = mode_env == 2 ? segclip_ablation_env("SEGCLIP_PQ_ABL") : 0;
   unsigned nwg = 0;
   if (!pq_tail_setup(g, d, stream, &nwg)) return false;
   (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3(nwg), stream, &g);
