@@ -374,8 +374,11 @@ def main():
                                                         find_unused_parameters=True, bucket_cap_mb=64, static_graph=True)
     batch = synth.synthetic_batch(spec, a.batch, seed=100 + rank, device=dev, with_seg=a.full_loss)
 
+    params = [p for p in model.parameters()]   # (Module.zero_grad walks the module tree: 1.8 ms of host time per step)
+
     def step():
-        net.zero_grad(set_to_none=True)
+        for p in params:
+            p.grad = None
         loss = net(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"],
                    image_seg=batch.get("image_seg"))
         loss.backward()

@@ -156,7 +156,15 @@ def check(rc, what):
         raise (Unsupported if rc == -2 else RuntimeError)(f"segclip_hip {what} failed (rc={rc}): {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  Called once per kernel launch (~800 per step): the raw
+    accessor avoids torch.cuda.current_stream()'s Python wrappers (9 us per call = 2 ms of host time per forward)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

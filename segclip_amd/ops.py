@@ -112,6 +112,9 @@ class ReduceQueue:
         self.slabs, self.rows, self.keep = [], [], []
 
 
+_PQ_TAIL_ENV = os.environ.get("SEGCLIP_PQ_TAIL", "0") not in ("", "0")
+
+
 def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -176,7 +179,10 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
             flags |= L.GEMM_DEFER_COLSUM
             defer.add_rows(csws, M // 64, N, N, (colsum,), N)
     ws = None
-    nbytes = lib.segclip_gemm_ws_bytes(C.byref(d))
+    # a workspace exists only for split-K (no epilogue operands) - or, with the tail-split experiment switched on, for any GEMM:
+    # skip the query call on the ~60 % of launches that can never have one (host time: the step is ~800 launches)
+    nbytes = (lib.segclip_gemm_ws_bytes(C.byref(d))
+              if (_PQ_TAIL_ENV or (bias is None and residual is None and aux is None and act == ACT_NONE and not mul_dact)) else 0)
     if nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = L.ptr(ws), nbytes

@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/r04; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED|^E " | head -20 > gpurun_out/r04/pytest_gpu.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i "smoke" > gpurun_out/r04/smoke.txt
-bash tools/profile_round.sh r04 > gpurun_out/r04/profile_round.log 2>&1
-cat gpurun_out/r04/pytest_gpu.txt gpurun_out/r04/smoke.txt; head -12 gpurun_out/r04/profile_round.log
+mkdir -p gpurun_out/r04p
+for B in 64 256; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps 20 --warmup 5 --batch $B 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('B=$B', d['ms_per_step'], d['value'], d['config']['loss'])"; done | tee gpurun_out/r04p/b.txt
+B=64 python tools/debug/host_lead.py 2>&1 | grep "host fwd" | tail -3 | tee -a gpurun_out/r04p/b.txt
+timeout 900 python -m pytest tests/test_model_gpu.py tests/test_streams_gpu.py tests/test_dist_gpu.py tests/test_train_gpu.py -x -q 2>&1 | grep -E "passed|failed|Error|FAILED|^E " | head -10 | tee -a gpurun_out/r04p/b.txt
