@@ -391,6 +391,23 @@ int segclip_clip_ce_fwd(const float* cos, const float* logit_scale, float* lse, 
 int segclip_clip_ce_bwd(const float* cos, const float* lse, const float* logit_scale, const float* g, float* dcos,
                         float* ds_rows, float* dlogit_scale, int64_t B, int64_t N, int64_t label_offset, void* stream);
 
+/* Segment mean of the learnable-center stage (reference modules/module_seg_vit.py:308-309):
+ *   out[b][g][:] = (sum_t [idx[b][t] == g] v[b][t][:]) / max(counts[b][g], 1)       (hard assignment = one-hot of idx)
+ * and its backward: dv[b][t][:] = dN[b][idx[b][t]][:], dhard[b][g][t] = dN[b][g] . v[b][t] + dc[b][g] with dN = dout / max(count, 1),
+ * dc = -[count >= 1] (dout[b][g] . out[b][g]) / max(count, 1).  idx (B,T) uint8, counts (B,G) fp32 as segclip_assign_fwd leaves
+ * them; v / dv (B,T,D) fp32 or bf16; out, dout (B,G,D) and dhard (B,G,T) fp32.  G <= 8, D a multiple of 4 (backward: D <= 1024). */
+int segclip_segmean_fwd(const uint8_t* idx, const void* v, int v_dtype, const float* counts, float* out, int64_t B, int64_t G,
+                        int64_t T, int64_t D, void* stream);
+int segclip_segmean_bwd(const float* dout, const float* out, const uint8_t* idx, const void* v, int v_dtype, const float* counts,
+                        void* dv, float* dhard, int64_t B, int64_t G, int64_t T, int64_t D, void* stream);
+
+/* Assignment logits of the center stage: attn[b][g][t] = q[b][g][:] . k[b][t][:] (fp32, un-scaled; reference
+ * modules/module_seg_vit.py:304) and the backward dq = dl k, dk = dl^T q.  Covers G = 8, D = 768 | 1024; other shapes return
+ * SEGCLIP_ERR_UNSUPPORTED (use segclip_gemm).  Not the summation order of the exact-fp32 GEMM. */
+int segclip_center_logits_fwd(const float* q, const float* k, float* attn, int64_t B, int64_t G, int64_t T, int64_t D, void* stream);
+int segclip_center_logits_bwd(const float* dl, const float* q, const float* k, float* dq, float* dk, int64_t B, int64_t G,
+                              int64_t T, int64_t D, void* stream);
+
 /* dst[i][:] = bf16(src[i][:]) for `count` fp32 tensors in ceil(count/32) launches (the compute-dtype copies of the
  * GEMM weights, refreshed once per forward instead of one cast launch per weight).  src/dst/n are HOST arrays. */
 int segclip_multi_cast_bf16(const float* const* src, void* const* dst, const int64_t* n, int64_t count, void* stream);

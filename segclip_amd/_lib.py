@@ -114,6 +114,10 @@ SIGNATURES = {
     "segclip_l2norm_pair_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, vp]),
     "segclip_clip_ce_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "segclip_clip_ce_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "segclip_segmean_fwd": (C.c_int, [vp, vp, C.c_int, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_segmean_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_center_logits_fwd": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_center_logits_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "segclip_group_linear64": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, i64, C.c_int, vp]),
     "segclip_grad_sqnorm_ws_bytes": (C.c_size_t, [vp, i64]),
     "segclip_grad_sqnorm": (C.c_int, [vp, vp, i64, vp, vp, f32, vp]),

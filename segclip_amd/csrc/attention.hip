@@ -326,6 +326,8 @@ constexpr int TMAX = 256;
 // the dQ pass in the same space) + lse, D, cs vectors + the cross-wave reduce pad
 static inline size_t bwd_lds_bytes(int tp) { return (size_t)tp * (2 * ROWB + 3 * 4) + 8 * 3 * 64 * 4; }
 
+#include "attention_smallq.inc"
+
 // MFMA operand fragment straight from global memory (rows that only ONE wave needs): lane l -> row row0 + (l&31),
 // cols kc*16 + 8*(l>>5) .. +7; zero beyond nvalid / hd.  Unconditional load from a clamped address + select.
 __device__ __forceinline__ bf16x8_t frag_rows_g(const bf16_t* __restrict__ X, int64_t st, int row0, int nvalid, int kc,
@@ -696,6 +698,13 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     static const int fwd_lean = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_LEAN"); return e ? atoi(e) : 1; }();
     a.lean = fwd_lean;
     SEGCLIP_REQUIRE(!(d->klen && (d->flags & SEGCLIP_ATTN_FP8)), "attn_fwd: klen is not supported by the fp8 kernel");
+    if (smallq::covers(d)) {   // at most 8 queries (the learnable-center cross-attention): one wave per (batch, head), VALU
+      const int nitems = (int)(d->B * d->H);
+      hipLaunchKernelGGL(smallq::attn_smallq_fwd_kernel, dim3((unsigned)cdiv(nitems, smallq::WPB_FWD)), dim3(smallq::WPB_FWD * 64),
+                         smallq::lds_bytes((int)d->Tk, false), stream, a, nitems);
+      SEGCLIP_CHECK_LAUNCH("attn_smallq_fwd");
+      return 0;
+    }
     const int tiles = (int)cdiv(d->Tq, 32);
     const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
     SEGCLIP_REQUIRE(d->B * d->H <= 65535, "attn_fwd: B*H too large");
@@ -754,6 +763,12 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     static const int abl_env = segclip_ablation_env("SEGCLIP_ATTN_ABL");
     a.abl = abl_env;
     a.nitems = (int)(d->B * d->H);
+    if (smallq::covers(d) && d->colsum_part == nullptr) {
+      hipLaunchKernelGGL(smallq::attn_smallq_bwd_kernel, dim3((unsigned)cdiv(a.nitems, smallq::WPB_BWD)), dim3(smallq::WPB_BWD * 64),
+                         smallq::lds_bytes((int)d->Tk, true), stream, a, a.nitems);
+      SEGCLIP_CHECK_LAUNCH("attn_smallq_bwd");
+      return 0;
+    }
     if (d->Tq > TMAX || d->Tk > TMAX) {
       SEGCLIP_REQUIRE(d->klen == nullptr, "attn_bwd bf16: klen needs sequences of at most %d tokens", TMAX);
       // long sequences: two streaming launches (dK,dV | dQ), 8 owned tiles per workgroup

@@ -264,8 +264,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_bf16_dma_kern
   if (variant == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128, 128, 4>), grid, dim3(256), 0, stream, g);      \
   else if (variant == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 256, 128, 8, 3>), grid, dim3(512), 0, stream, g); \
   else
-#else
-#define DMA_EXP(AK, BKS)
+#else   // production: the 128x128 / 4-wave tile for problems too small to fill the chip with 256-row tiles (round 4)
+#define DMA_EXP(AK, BKS)                                                                                        \
+  if (variant == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKS, 128, 128, 4>), grid, dim3(256), 0, stream, g);      \
+  else
 #endif
 #define DMA_LAUNCHER(NAME, AK, BKS)                                                                             \
   void NAME(int variant, dim3 grid, hipStream_t stream, const void* args) {                                     \
@@ -324,14 +326,22 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   // loses 5-15 % on long-K dgrads and every split-K wgrad; inside the training step (text tower concurrent on a
   // second stream) a shape-based choice measured 58.4 vs 58.2 ms, i.e. no gain, so the 256-wide tiles stay the
   // default and SEGCLIP_GEMM_TILE=128 selects this variant for experiments.
-#ifdef SEGCLIP_GEMM_EXPERIMENTS  // build.sh -DSEGCLIP_GEMM_EXPERIMENTS: 8 more kernel instances (+3 min of hipcc time)
+  // Round 4: problems whose 256-row tiles cannot fill the 256 CUs (the center stage's q-side linears: M = 8 B = 2048 rows,
+  // 48-192 tiles) take the 128x128 tile: four times the workgroups, two per CU, half the K-loop time per tile
+  // (SEGCLIP_GEMM_SMALL_TILES=0 switches the rule off; a forward + backward pass of the center stage: see DESIGN 4.4).
+  static const int small_rule = [] { const char* e = getenv("SEGCLIP_GEMM_SMALL_TILES"); return e ? atoi(e) : 1; }();
+  const int bn_big = pick_bn(d, nb * splits);
+  const bool auto_small = small_rule && d->M >= 128 && d->N >= 128 && !(d->aux_kind == 2 && d->aux) && !g.colsum_part &&
+                          cdiv(d->M, 256) * cdiv(d->N, bn_big) * nb * splits < 256;
+#ifdef SEGCLIP_GEMM_EXPERIMENTS  // build.sh -DSEGCLIP_GEMM_EXPERIMENTS: the 3-stage-ring instances (+ hipcc time)
   static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  const bool small = force_tile == 128;
+  const bool small = force_tile == 128 || (force_tile == 0 && auto_small);
   const bool three = force_tile == 3;  // experiment: 256x128 tiles with a 3-stage ring (96 KiB in flight)
 #else
-  constexpr bool small = false, three = false;
+  const bool small = auto_small;
+  constexpr bool three = false;
 #endif
-  const int bn = (small || three) ? 128 : pick_bn(d, nb * splits);
+  const int bn = (small || three) ? 128 : bn_big;
   const int bm = small ? 128 : 256;
   g.nbx = (int)cdiv(d->N, bn);
   g.nby = (int)cdiv(d->M, bm);

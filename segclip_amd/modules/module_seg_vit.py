@@ -243,11 +243,14 @@ class SemanticLearnerModule(nn.Module):
         k = ops.layer_norm(k, self.k_ln.weight, self.k_ln.bias, self.k_ln.eps, torch.float32).view(B, T, D)
         v = v.view(B, T, D)
         # assignment logits always in exact fp32 (bit-exact argmax), un-scaled (module_seg_vit.py:304)
-        attn = ops.bmm(q, k, transB=True, out_dtype=torch.float32)
+        attn = ops.center_logits(q, k, exact=ad != torch.bfloat16)
         g = config.gumbel((B, G, T), inputs.device) if self.training else None
-        hard_attn, soft_attn, idx = ops.AssignFn.apply(attn, g, 0.9)
-        cnt = torch.clamp_min(hard_attn.sum(dim=-1, keepdim=True), 1.0)
-        outputs = ops.bmm(hard_attn.to(ad), v, transB=False, out_dtype=torch.float32) / cnt
+        hard_attn, soft_attn, idx, counts = ops.AssignFn.apply(attn, g, 0.9)
+        if G <= 8 and D <= 1024:      # segment mean by center index: one launch each way (csrc/center.hip)
+            outputs = ops.SegMeanFn.apply(hard_attn, idx, counts, v)
+        else:
+            cnt = torch.clamp_min(hard_attn.sum(dim=-1, keepdim=True), 1.0)
+            outputs = ops.bmm(hard_attn.to(ad), v, transB=False, out_dtype=torch.float32) / cnt
         z = ops.layer_norm(q + outputs, self.proj_o.ln.weight, self.proj_o.ln.bias, self.proj_o.ln.eps, ad)
         outputs = self.proj_o.mlp(z, final_act=ops.ACT_QUICK_GELU, out_dtype=torch.float32)
         self.last_hard_idx = idx

@@ -1104,11 +1104,11 @@ class AssignFn(Function):
                 "assign_fwd")
         ctx.save_for_backward(y)
         ctx.tau = tau if g is not None else 1.0
-        ctx.mark_non_differentiable(soft, idx)
-        return hard, soft, idx
+        ctx.mark_non_differentiable(soft, idx, counts)
+        return hard, soft, idx, counts
 
     @staticmethod
-    def backward(ctx, dhard, _dsoft, _didx):
+    def backward(ctx, dhard, _dsoft, _didx, _dcounts):
         (y,) = ctx.saved_tensors
         B, G, T = y.shape
         dhard = dhard.contiguous()
@@ -1494,3 +1494,70 @@ class ClipLossFn(Function):
             L.check(lib.segclip_l2norm_pair_bwd(L.ptr(dboth), L.ptr(dloc), L.ptr(both), L.ptr(norms), L.ptr(dv), L.ptr(dt), B, C,
                                                 L.stream()), "l2norm_pair_bwd")
         return dv, dt, dls, None, None
+
+
+class SegMeanFn(Function):
+    """outputs = (hard @ v) / clamp_min(hard.sum(-1), 1)  (modules/module_seg_vit.py:308-309) for the one-hot hard assignment
+    of AssignFn: a segment mean by center index in one launch, and its backward (dv, and dhard through numerator and
+    normaliser) in one launch.  hard (B,G,T) fp32 carries the straight-through gradient; idx (B,T) uint8 and counts (B,G) are
+    AssignFn's; v (B,T,D) fp32 or bf16.  -> (B,G,D) fp32."""
+
+    @staticmethod
+    def forward(ctx, hard, idx, counts, v):
+        B, G, T = hard.shape
+        D = v.shape[2]
+        v = v.contiguous()
+        L.require_cuda(hard, idx, counts, v)
+        out = _empty((B, G, D), torch.float32, v)
+        L.check(L.load().segclip_segmean_fwd(L.ptr(idx), L.ptr(v), L.dt(v), L.ptr(counts), L.ptr(out), B, G, T, D, L.stream()), "segmean_fwd")
+        ctx.save_for_backward(idx, counts, v, out)
+        ctx.shape = (B, G, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, counts, v, out = ctx.saved_tensors
+        B, G, T, D = ctx.shape
+        dout = dout.contiguous().float()
+        dv = torch.empty_like(v)
+        dhard = _empty((B, G, T), torch.float32, v)
+        L.check(L.load().segclip_segmean_bwd(L.ptr(dout), L.ptr(out), L.ptr(idx), L.ptr(v), L.dt(v), L.ptr(counts), L.ptr(dv), L.ptr(dhard),
+                                             B, G, T, D, L.stream()), "segmean_bwd")
+        return dhard, None, None, dv
+
+
+class CenterLogitsFn(Function):
+    """Assignment logits of the learnable-center stage, attn = q k^T un-scaled (modules/module_seg_vit.py:304): q (B,G,D), k (B,T,D),
+    both fp32 -> (B,G,T) fp32, and dq = dattn k, dk = dattn^T q, as per-sample token loops (csrc/center.hip) instead of batched
+    M = 8 products on 32-row MFMA tiles (3 launches of 110-140 us).  The summation order over D is not the exact-fp32 GEMM's:
+    the module uses this in bf16 mode only (the exact-f32 mode keeps the GEMM, whose argmax the parity tests pin)."""
+
+    @staticmethod
+    def forward(ctx, q, k):
+        q, k = q.contiguous().float(), k.contiguous().float()
+        B, G, D = q.shape
+        T = k.shape[1]
+        L.require_cuda(q, k)
+        attn = _empty((B, G, T), torch.float32, q)
+        L.check(L.load().segclip_center_logits_fwd(L.ptr(q), L.ptr(k), L.ptr(attn), B, G, T, D, L.stream()), "center_logits_fwd")
+        ctx.save_for_backward(q, k)
+        return attn
+
+    @staticmethod
+    def backward(ctx, dattn):
+        q, k = ctx.saved_tensors
+        B, G, D = q.shape
+        T = k.shape[1]
+        dattn = dattn.contiguous().float()
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        L.check(L.load().segclip_center_logits_bwd(L.ptr(dattn), L.ptr(q), L.ptr(k), L.ptr(dq), L.ptr(dk), B, G, T, D, L.stream()),
+                "center_logits_bwd")
+        return dq, dk
+
+
+def center_logits(q, k, exact):
+    """(B,G,T) fp32 assignment logits; exact=True (the exact-f32 mode) or uncovered shapes: the exact-fp32 batched GEMM"""
+    B, G, D = q.shape
+    if not exact and G == 8 and D in (768, 1024) and k.shape[1] * 32 <= 60000:
+        return CenterLogitsFn.apply(q, k)
+    return bmm(q, k, transB=True, out_dtype=torch.float32)

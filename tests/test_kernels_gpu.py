@@ -478,7 +478,8 @@ def test_center_assignment_bit_exact(train):
     B, G, T = 4, 8, 196
     logits = rnd(B, G, T, seed=101, scale=5.0).requires_grad_()
     gum = rnd(B, G, T, seed=102) if train else None
-    hard, soft, idx = ops.AssignFn.apply(logits, gum, 0.9)
+    hard, soft, idx, counts = ops.AssignFn.apply(logits, gum, 0.9)
+    assert torch.equal(counts, hard.detach().sum(-1))
     lr = logits.detach().clone().requires_grad_()
     y = ((lr + gum) / 0.9).softmax(1) if train else lr.softmax(1)
     index = y.max(1, keepdim=True)[1]
@@ -818,6 +819,50 @@ def test_fused_contrastive_head(B, C):
         close(tt.grad, tr.grad, 1e-3, 2e-6, "d text feature")
         assert abs(float(ls.grad) - float(lr.grad)) <= 1e-4 * max(1.0, abs(float(lr.grad))), (float(ls.grad), float(lr.grad))
         close(sc.detach() * box["cos"][0], t2v.detach(), 1e-5, 1e-4, "t2v logits")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("B,T,D", [(5, 196, 768), (3, 49, 1024), (2, 7, 64)])
+def test_segment_mean_of_center_stage(dtype, B, T, D):
+    """outputs = (hard @ v) / clamp_min(hard.sum(-1), 1) (modules/module_seg_vit.py:308-309) as a segment mean by center index
+    (ops.SegMeanFn) against the torch expression on the same hard assignment: forward, dv, and dhard through numerator and
+    normaliser; one center is left EMPTY (count 0: clamp active, no gradient through the normaliser)."""
+    G = 8
+    logits = rnd(B, G, T, seed=103, scale=3.0)
+    logits[:, 5] = -50.0                                      # center 5 never wins: empty segment
+    hard, soft, idx, counts = ops.AssignFn.apply(logits, None, 1.0)
+    assert float(counts[:, 5].abs().max()) == 0.0
+    v = rnd(B, T, D, dtype=dtype, seed=104)
+    go = rnd(B, G, D, seed=105)
+    h1 = hard.detach().clone().requires_grad_()
+    v1 = v.detach().clone().requires_grad_()
+    out = ops.SegMeanFn.apply(h1, idx, counts, v1)
+    out.backward(go)
+    h2 = hard.detach().clone().requires_grad_()
+    v2 = v.detach().float().requires_grad_()
+    ref = (h2 @ v2) / torch.clamp_min(h2.sum(-1, keepdim=True), 1.0)
+    ref.backward(go)
+    close(out, ref, 1e-5, 1e-5, "segment mean")
+    tol = 1e-5 if dtype == F32 else 1e-2
+    close(v1.grad, v2.grad, tol, tol, "dv")
+    close(h1.grad, h2.grad, 1e-4, 1e-4 * D ** 0.5, "dhard")
+
+
+@pytest.mark.parametrize("B,T,D", [(4, 196, 768), (2, 576, 1024), (3, 48, 768)])
+def test_center_assignment_logits_token_loop(B, T, D):
+    """attn = q k^T (un-scaled, fp32; modules/module_seg_vit.py:304) and its backward as per-sample token loops
+    (ops.CenterLogitsFn, the bf16 mode's path) against torch in fp64."""
+    G = 8
+    q, k = rnd(B, G, D, seed=106).requires_grad_(), rnd(B, T, D, seed=107).requires_grad_()
+    go = rnd(B, G, T, seed=108)
+    attn = ops.CenterLogitsFn.apply(q, k)
+    attn.backward(go)
+    q2, k2 = q.detach().double().requires_grad_(), k.detach().double().requires_grad_()
+    ref = q2 @ k2.transpose(1, 2)
+    ref.backward(go.double())
+    close(attn, ref, 1e-5, 1e-4, "logits")
+    close(q.grad, q2.grad, 1e-5, 1e-4, "dq")
+    close(k.grad, k2.grad, 1e-5, 1e-4, "dk")
 
 
 def test_deferred_reductions_are_bit_identical():
