@@ -147,6 +147,33 @@ int segclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, con
                           const float* rstd, const void* dres, void* dx, void* dx_bf16, float* dgamma,
                           float* dbeta, float* dres_colsum, void* ws, int64_t rows, int64_t cols, int dy_dtype,
                           int x_dtype, int dx_dtype, void* stream);
+/* Row-mapped variants: row r of the kernel's row space is row (r / seg_in) * seg_out + seg_off + r % seg_in of y
+ * (forward) / of dy (backward); x, mean, rstd, dres, dx keep plain rows.  LayerNorm(cat([centers, tokens], dim=1))
+ * without the concatenated copy - modules/module_seg_vit.py:294-296 (`kv = torch.cat([q, inputs], dim=1)`) with
+ * :211 (`self.ln_1(k)`): one call per part writes its token slice of every sample of the (B, seg_out, cols) buffer. */
+int segclip_layernorm_fwd_seg(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                              float* rstd, int64_t rows, int64_t cols, float eps, int x_dtype, int y_dtype,
+                              int64_t seg_in, int64_t seg_out, int64_t seg_off, void* stream);
+int segclip_layernorm_bwd_seg(const void* dy, const void* x, const float* gamma, const float* mean,
+                              const float* rstd, const void* dres, void* dx, void* dx_bf16, float* dgamma,
+                              float* dbeta, float* dres_colsum, void* ws, int64_t rows, int64_t cols, int dy_dtype,
+                              int x_dtype, int dx_dtype, int64_t seg_in, int64_t seg_out, int64_t seg_off,
+                              void* stream);
+
+/* Three affine outputs of ONE normalisation (n must be 3; fp32 x; cols 768 or 1024; y / dy all fp32 or all bf16 - otherwise
+ * SEGCLIP_ERR_UNSUPPORTED and nothing is launched).  The learnable-center stage normalises the same token rows with
+ * `self.norm` (modules/module_seg_vit.py:289) and with `ln_1` of both cross-attention layers (:211 over :294-296): one
+ * read of x in the forward, and ONE dx = sum of the three LayerNorm backwards in the backward.
+ * gamma / beta / y / dy: arrays of n device pointers; maps: n x {seg_in, seg_out, seg_off} (seg_in = 0: identity) - the row
+ * mapping of output k / gradient k as in segclip_layernorm_fwd_seg.
+ * dgb: (2n, cols) fp32 <- [dgamma_0, dbeta_0, dgamma_1, dbeta_1, ...];  ws: segclip_layernorm_bwd_multi_ws_bytes. */
+int segclip_layernorm_fwd_multi(const void* x, int n, const float* const* gamma, const float* const* beta,
+                                void* const* y, const int64_t* maps, float* mean, float* rstd, int64_t rows,
+                                int64_t cols, float eps, int x_dtype, int y_dtype, void* stream);
+size_t segclip_layernorm_bwd_multi_ws_bytes(int64_t rows, int64_t cols, int n);
+int segclip_layernorm_bwd_multi(const void* const* dy, const void* x, int n, const float* const* gamma,
+                                const int64_t* maps, const float* mean, const float* rstd, void* dx, float* dgb,
+                                void* ws, int64_t rows, int64_t cols, int dy_dtype, int x_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention core  O = softmax(scale * Q K^T [+ causal mask]) V,  head_dim <= 64.

@@ -75,6 +75,12 @@ SIGNATURES = {
     "segclip_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),
     "segclip_layernorm_bwd_ws_bytes": (C.c_size_t, [i64, i64]),
     "segclip_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "segclip_layernorm_fwd_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),
+    "segclip_layernorm_bwd_multi_ws_bytes": (C.c_size_t, [i64, i64, C.c_int]),
+    "segclip_layernorm_bwd_multi": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, vp]),
+    "segclip_layernorm_fwd_seg": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, i64, i64, i64, vp]),
+    "segclip_layernorm_bwd_seg": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int,
+                                            i64, i64, i64, vp]),
     "segclip_attn_stats_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "segclip_attn_bwd_ws_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "segclip_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),

@@ -78,13 +78,21 @@ class CrossAttentionBlock(nn.Module):
         self.mlp = _mlp_sequential(d_model)
         self.ln_2 = LayerNorm(d_model)
 
-    def forward(self, q, k):
+    def forward(self, q, k, k_tail=None, kn_buf=None):
+        """The key/value input is k, or cat([k, k_tail], dim=1) when k_tail is given - never materialised: ln_k writes
+        both parts into one buffer (ops.LayerNormCatFn), or, with kn_buf (B, S, D) whose tail rows already hold
+        ln_k(k_tail) (ops.LayerNormMultiFn), only the head rows ln_k(k)."""
         B, G, D = q.shape
-        S = k.shape[1]
         ad = config.compute_dtype
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         qn = self.ln_x(q)
-        kn = self.ln_k(k)
+        if kn_buf is not None:
+            kn = ops.layer_norm_into(kn_buf, k, self.ln_k.weight, self.ln_k.bias, self.ln_k.eps, 0)
+        elif k_tail is None:
+            kn = self.ln_k(k)
+        else:
+            kn = ops.layer_norm_cat(k, k_tail, self.ln_k.weight, self.ln_k.bias, self.ln_k.eps, ad)
+        S = kn.shape[1]
         qp = ops.linear(qn, w[:D], b[:D], act_dtype=ad).view(B * G, D)
         kvp = ops.linear(kn, w[D:], b[D:], act_dtype=ad).view(B * S, 2 * D)
         o = ops.CrossAttnFn.apply(qp, kvp, B, G, S, self.n_head, config.cross_mode).view(B, G, D)
@@ -232,11 +240,23 @@ class SemanticLearnerModule(nn.Module):
         G = self.semantic_center.shape[0]
         ad = config.compute_dtype
         inputs = inputs.float()
-        n = ops.layer_norm(inputs, self.norm.weight, self.norm.bias, self.norm.eps, ad)
         q = self.semantic_center.float().unsqueeze(0).expand(B, G, D).contiguous()
-        for blk in self.cross_att:
-            kv = torch.cat([q, inputs], dim=1)
-            q = blk(q, kv)
+        # `self.norm(inputs)` and the token part of `ln_1(kv)`, kv = torch.cat([q, inputs], dim=1), of every cross layer
+        # normalise the same rows: one kernel, three affine outputs (and one dx in the backward); kv is never built
+        multi = None
+        blocks = list(self.cross_att)
+        if len(blocks) == 2 and all(blk.ln_k.eps == self.norm.eps for blk in blocks):
+            multi = ops.layer_norm_multi(inputs.reshape(B * T, D),
+                                         [(self.norm.weight, self.norm.bias)] + [(blk.ln_k.weight, blk.ln_k.bias) for blk in blocks],
+                                         [None, (T, G + T, G), (T, G + T, G)], self.norm.eps, ad)
+        if multi is not None:
+            n = multi[0].view(B, T, D)
+            for blk, buf in zip(blocks, multi[1:]):
+                q = blk(q, q, kn_buf=buf)
+        else:
+            n = ops.layer_norm(inputs, self.norm.weight, self.norm.bias, self.norm.eps, ad)
+            for blk in blocks:
+                q = blk(q, q, inputs)
         q = ops.layer_norm(q, self.cross_ln.weight, self.cross_ln.bias, self.cross_ln.eps, torch.float32)
         n2 = n.view(B * T, D)
         k, v = _group_linear_pair(n2, self.k_conv.weight, self.v_conv.weight, self.num_heads)

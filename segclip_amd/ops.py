@@ -326,24 +326,36 @@ def p_colsum(x, out=None):
     return out
 
 
-def p_ln_fwd(x, w, b, eps, out_dtype):
+def p_ln_fwd(x, w, b, eps, out_dtype, out=None, seg=None):
+    """seg = (seg_in, seg_out, off) with out = a (n * seg_out, cols) buffer: row r of x is written to row
+    (r // seg_in) * seg_out + off + r % seg_in of out (LayerNorm into a token slice of every sample)."""
     x = x.contiguous()
     rows, cols = x.shape
-    y = _empty((rows, cols), out_dtype, x)
+    y = out if out is not None else _empty((rows, cols), out_dtype, x)
     mean = _empty((rows,), torch.float32, x)
     rstd = _empty((rows,), torch.float32, x)
     if _OpCount.enabled:
         _OpCount.add("ln_fwd", 0, rows * cols * (x.element_size() + y.element_size()))
-    L.check(L.load().segclip_layernorm_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows,
-                                           cols, eps, L.dt(x), L.dt(y), L.stream()), "layernorm_fwd")
+    if seg is None:
+        L.check(L.load().segclip_layernorm_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows,
+                                               cols, eps, L.dt(x), L.dt(y), L.stream()), "layernorm_fwd")
+    else:
+        if out is None or not out.is_contiguous() or rows % seg[0] or out.numel() != rows // seg[0] * seg[1] * cols:
+            raise ValueError("layernorm_fwd_seg: out must be the contiguous (rows / seg_in * seg_out, cols) buffer")
+        L.check(L.load().segclip_layernorm_fwd_seg(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows,
+                                                   cols, eps, L.dt(x), L.dt(y), seg[0], seg[1], seg[2], L.stream()),
+                "layernorm_fwd_seg")
     return y, mean, rstd
 
 
 def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, want_dres_colsum=False, outs=(None, None, None),
-             defer=None):
-    """-> dx, dgamma, dbeta [, dx_bf16] [, colsum(dres)];  outs = preallocated (dgamma, dbeta, colsum) buffers or None"""
+             defer=None, seg=None):
+    """-> dx, dgamma, dbeta [, dx_bf16] [, colsum(dres)];  outs = preallocated (dgamma, dbeta, colsum) buffers or None.
+    seg = (seg_in, seg_out, off): the rows of dy are mapped like the output of p_ln_fwd(seg=...)."""
     lib = L.load()
     dy = dy.contiguous()
+    if seg is not None and (x.shape[0] % seg[0] or dy.numel() != x.shape[0] // seg[0] * seg[1] * x.shape[1]):
+        raise ValueError("layernorm_bwd_seg: dy must be the contiguous (rows / seg_in * seg_out, cols) buffer")
     rows, cols = x.shape
     dx_dtype = dx_dtype or x.dtype
     dx = _empty((rows, cols), dx_dtype, x)
@@ -363,9 +375,15 @@ def p_ln_bwd(dy, x, w, mean, rstd, dres=None, dx_dtype=None, want_bf16=False, wa
     wsb = lib.segclip_layernorm_bwd_ws_bytes(rows, cols)
     ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=x.device)
     deferred = defer is not None and rows > 0 and all(t.data_ptr() % 16 == 0 for t in (dw, db) + ((dsum,) if dsum is not None else ()))
-    L.check(lib.segclip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
-                                      L.ptr(dx16), None if deferred else L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws), rows, cols,
-                                      L.dt(dy), L.dt(x), L.dt(dx), L.stream()), "layernorm_bwd")
+    if seg is None:
+        L.check(lib.segclip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
+                                          L.ptr(dx16), None if deferred else L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws), rows,
+                                          cols, L.dt(dy), L.dt(x), L.dt(dx), L.stream()), "layernorm_bwd")
+    else:
+        L.check(lib.segclip_layernorm_bwd_seg(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
+                                              L.ptr(dx16), None if deferred else L.ptr(dw), L.ptr(db), L.ptr(dsum), L.ptr(ws),
+                                              rows, cols, L.dt(dy), L.dt(x), L.dt(dx), seg[0], seg[1], seg[2], L.stream()),
+                "layernorm_bwd_seg")
     if deferred:   # ws = [blocks][dgamma | dbeta | colsum(dres)] partial rows
         defer.add_rows(ws, wsb // (3 * cols * 4), (3 if dsum is not None else 2) * cols, 3 * cols, (dw, db, dsum), cols)
     out = [dx, dw, db]
@@ -528,6 +546,138 @@ class LayerNormFn(Function):
         x, w, mean, rstd = ctx.saved_tensors
         dx, dw, db = p_ln_bwd(dy, x, w, mean, rstd, None, x.dtype)[:3]
         return dx, dw, db, None, None
+
+
+class LayerNormCatFn(Function):
+    """LayerNorm(cat([a, b], dim=1)) for a (B, Ta, D), b (B, Tb, D) WITHOUT the concatenated copy: each part is
+    normalised straight into its token slice of the (B, Ta+Tb, D) result, and the backward reads each part's
+    gradient from the slice.  The learnable-center cross-attention normalises cat([centers, tokens]) as its K/V input
+    in both of its layers (reference modules/module_seg_vit.py:294-296 `kv = torch.cat([q, inputs], dim=1)`, :211
+    `self.ln_1(k)`): 2 x (B*204*768 fp32 copy forward + its slice-copy backward) per step."""
+
+    @staticmethod
+    def forward(ctx, a, b, w, bias, eps, out_dtype):
+        B, Ta, D = a.shape
+        Tb = b.shape[1]
+        S = Ta + Tb
+        a2, b2 = a.reshape(B * Ta, D), b.reshape(B * Tb, D)
+        y = _empty((B * S, D), out_dtype, a)
+        _, ma, ra = p_ln_fwd(a2, w, bias, eps, out_dtype, out=y, seg=(Ta, S, 0))
+        _, mb, rb = p_ln_fwd(b2, w, bias, eps, out_dtype, out=y, seg=(Tb, S, Ta))
+        ctx.save_for_backward(a2, b2, w, ma, ra, mb, rb)
+        ctx.dims = (B, Ta, Tb, D)
+        return y.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, b2, w, ma, ra, mb, rb = ctx.saved_tensors
+        B, Ta, Tb, D = ctx.dims
+        S = Ta + Tb
+        dy = dy.contiguous().view(B * S, D)
+        da, dwa, dba = p_ln_bwd(dy, a2, w, ma, ra, None, a2.dtype, seg=(Ta, S, 0))[:3]
+        db_, dwb, dbb = p_ln_bwd(dy, b2, w, mb, rb, None, b2.dtype, seg=(Tb, S, Ta))[:3]
+        dwa += dwb
+        dba += dbb
+        return da.view(B, Ta, D), db_.view(B, Tb, D), dwa, dba, None, None
+
+
+def _ptr_array(tensors):
+    L.require_cuda(*tensors)
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _seg_maps(segs):
+    flat = []
+    for sg in segs:
+        flat += [0, 0, 0] if sg is None else [int(v) for v in sg]
+    return (C.c_int64 * len(flat))(*flat)
+
+
+class LayerNormMultiFn(Function):
+    """y_k = LayerNorm(x; w_k, b_k), k < 3, from ONE read of x (rows, D) fp32 and one (mean, rstd); backward: one dx = sum
+    of the three LayerNorm backwards.  segs[k] = None (y_k is (rows, D)) or (seg_in, seg_out, off): y_k is a
+    (rows / seg_in, seg_out, D) buffer of which only the token slice [off, off + seg_in) of every sample is written - the
+    rest is filled in place later (LayerNormIntoFn), and the matching rows of its gradient are ignored here.
+    The learnable-center stage: `self.norm(inputs)` + `ln_1(cat([q, inputs]))` of both cross-attention layers
+    (reference modules/module_seg_vit.py:289,294-296,211)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, out_dtype, segs, *wb):
+        rows, D = x.shape
+        lib = L.load()
+        ys = [_empty((rows, D) if sg is None else (rows // sg[0], sg[1], D), out_dtype, x) for sg in segs]
+        mean = _empty((rows,), torch.float32, x)
+        rstd = _empty((rows,), torch.float32, x)
+        ws, bs = wb[0::2], wb[1::2]
+        L.check(lib.segclip_layernorm_fwd_multi(L.ptr(x), len(segs), _ptr_array(ws), _ptr_array(bs), _ptr_array(ys),
+                                                _seg_maps(segs), L.ptr(mean), L.ptr(rstd), rows, D, eps, L.dt(x), L.dt(ys[0]),
+                                                L.stream()), "layernorm_fwd_multi")
+        if _OpCount.enabled:
+            _OpCount.add("ln_fwd", 0, rows * D * (x.element_size() + len(segs) * ys[0].element_size()))
+        ctx.save_for_backward(x, mean, rstd, *ws)
+        ctx.segs, ctx.out_dtype = segs, out_dtype
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, mean, rstd = ctx.saved_tensors[:3]
+        ws = ctx.saved_tensors[3:]
+        rows, D = x.shape
+        n = len(ctx.segs)
+        lib = L.load()
+        dys = [dy.contiguous() if dy is not None else
+               torch.zeros((rows, D) if sg is None else (rows // sg[0], sg[1], D), dtype=ctx.out_dtype, device=x.device)
+               for dy, sg in zip(dys, ctx.segs)]
+        dx = torch.empty_like(x)
+        dgb = _empty((2 * n, D), torch.float32, x)
+        wsb = torch.empty(max(lib.segclip_layernorm_bwd_multi_ws_bytes(rows, D, n), 4), dtype=torch.uint8, device=x.device)
+        if _OpCount.enabled:
+            _OpCount.add("ln_bwd", 0, rows * D * (2 * x.element_size() + n * dys[0].element_size()))
+        L.check(lib.segclip_layernorm_bwd_multi(_ptr_array(dys), L.ptr(x), n, _ptr_array(ws), _seg_maps(ctx.segs), L.ptr(mean),
+                                                L.ptr(rstd), L.ptr(dx), L.ptr(dgb), L.ptr(wsb), rows, D, L.dt(dys[0]), L.dt(x),
+                                                L.stream()), "layernorm_bwd_multi")
+        return (dx, None, None, None) + tuple(dgb[i] for i in range(2 * n))
+
+
+def layer_norm_multi(x, affines, segs, eps, out_dtype):
+    """-> tuple of outputs, or None when the library has no kernel for this combination (run the single LayerNorms)."""
+    wb = [t for w, b in affines for t in (w, b)]
+    try:
+        return LayerNormMultiFn.apply(x.contiguous(), float(eps), out_dtype, tuple(segs), *wb)
+    except L.Unsupported:
+        return None
+
+
+class LayerNormIntoFn(Function):
+    """buf[:, off:off+Ta] = LayerNorm(a) IN PLACE, for a (B, Ta, D) and a (B, S, D) buffer whose other token rows are
+    already final (LayerNormMultiFn).  The gradient of buf passes through unchanged: its consumer ignores these rows."""
+
+    @staticmethod
+    def forward(ctx, buf, a, w, bias, eps, off):
+        B, S, D = buf.shape
+        Ta = a.shape[1]
+        a2 = a.reshape(B * Ta, D)
+        _, m, r = p_ln_fwd(a2, w, bias, eps, buf.dtype, out=buf.view(B * S, D), seg=(Ta, S, off))
+        ctx.mark_dirty(buf)
+        ctx.save_for_backward(a2, w, m, r)
+        ctx.dims = (B, S, Ta, D, off)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        a2, w, m, r = ctx.saved_tensors
+        B, S, Ta, D, off = ctx.dims
+        dbuf = dbuf.contiguous()
+        da, dw, db = p_ln_bwd(dbuf.view(B * S, D), a2, w, m, r, None, a2.dtype, seg=(Ta, S, off))[:3]
+        return dbuf, da.view(B, Ta, D), dw, db, None, None
+
+
+def layer_norm_into(buf, a, w, bias, eps, off=0):
+    return LayerNormIntoFn.apply(buf, a.contiguous(), w, bias, float(eps), int(off))
+
+
+def layer_norm_cat(a, b, w, bias, eps=1e-5, out_dtype=None):
+    return LayerNormCatFn.apply(a.contiguous(), b.contiguous(), w, bias, eps, out_dtype or a.dtype)
 
 
 def layer_norm(x, w, b, eps=1e-5, out_dtype=None):

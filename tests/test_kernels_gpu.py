@@ -897,3 +897,75 @@ def test_deferred_reductions_are_bit_identical():
     for a_, b_ in zip(r3, r2):
         assert torch.equal(a_, b_)
     assert torch.equal(du0, du1) and torch.equal(cs0, cs1)
+
+
+@pytest.mark.parametrize("out_dtype", [F32, BF])
+@pytest.mark.parametrize("B,Ta,Tb,D", [(5, 8, 196, 768), (3, 8, 49, 1024), (2, 3, 5, 64)])
+def test_layernorm_of_concatenation_without_the_copy(out_dtype, B, Ta, Tb, D):
+    """LayerNorm(cat([a, b], dim=1)) with each part written into its token slice (ops.LayerNormCatFn; reference
+    modules/module_seg_vit.py:294-296 + :211) against torch on the concatenated tensor: y, da, db, dgamma, dbeta."""
+    a, b = rnd(B, Ta, D, seed=111), rnd(B, Tb, D, seed=112)
+    w, bias = (1.0 + 0.1 * rnd(D, seed=113)), 0.1 * rnd(D, seed=114)
+    go = rnd(B, Ta + Tb, D, seed=115)
+    t1 = [t.detach().clone().requires_grad_() for t in (a, b, w, bias)]
+    y = ops.layer_norm_cat(t1[0], t1[1], t1[2], t1[3], 1e-5, out_dtype)
+    assert y.shape == (B, Ta + Tb, D) and y.dtype == out_dtype
+    y.backward(go.to(out_dtype))
+    t2 = [t.detach().double().requires_grad_() for t in (a, b, w, bias)]
+    ref = torch.nn.functional.layer_norm(torch.cat([t2[0], t2[1]], 1), (D,), t2[2], t2[3], 1e-5)
+    ref.backward(go.to(out_dtype).double())
+    tol = 2e-5 if out_dtype == F32 else 2e-2
+    close(y.float(), ref.float(), tol, tol, "y")
+    for name, g1, g2 in zip(("da", "db", "dgamma", "dbeta"), t1, t2):
+        close(g1.grad, g2.grad.float(), 1e-4, 1e-4 * (B * (Ta + Tb)) ** 0.5, name)
+
+
+@pytest.mark.parametrize("out_dtype", [F32, BF])
+@pytest.mark.parametrize("B,T,D", [(5, 196, 768), (2, 576, 1024), (1, 3, 768)])
+def test_three_affine_layernorms_share_one_normalisation(out_dtype, B, T, D):
+    """ops.LayerNormMultiFn + LayerNormIntoFn (the center stage's `norm` and both `ln_1(cat([q, tokens]))`,
+    modules/module_seg_vit.py:289,294-296,211) against three separate torch LayerNorms in fp64: the three outputs (two of
+    them token slices of (B, G+T, D) buffers completed in place by the center rows), ONE dx = the sum of the three
+    backwards, the center-row gradients, and every dgamma / dbeta (ln_1's accumulate the token and the center part)."""
+    G = 8
+    x = rnd(B, T, D, seed=121)
+    qs = [rnd(B, G, D, seed=122 + k) for k in range(2)]
+    ws = [(1.0 + 0.1 * rnd(D, seed=125 + k)) for k in range(3)]
+    bs = [0.1 * rnd(D, seed=128 + k) for k in range(3)]
+    gos = [rnd(B, T, D, seed=131), rnd(B, G + T, D, seed=132), rnd(B, G + T, D, seed=133)]
+    gos = [g.to(out_dtype) for g in gos]
+    x1 = x.detach().clone().requires_grad_()
+    q1 = [q.detach().clone().requires_grad_() for q in qs]
+    w1 = [w.detach().clone().requires_grad_() for w in ws]
+    b1 = [b.detach().clone().requires_grad_() for b in bs]
+    outs = ops.layer_norm_multi(x1.view(B * T, D), list(zip(w1, b1)), [None, (T, G + T, G), (T, G + T, G)], 1e-5, out_dtype)
+    assert outs is not None
+    n = outs[0].view(B, T, D)
+    k0 = ops.layer_norm_into(outs[1], q1[0], w1[1], b1[1], 1e-5, 0)
+    k1 = ops.layer_norm_into(outs[2], q1[1], w1[2], b1[2], 1e-5, 0)
+    torch.autograd.backward([n, k0, k1], gos)
+    x2 = x.detach().double().requires_grad_()
+    q2 = [q.detach().double().requires_grad_() for q in qs]
+    w2 = [w.detach().double().requires_grad_() for w in ws]
+    b2 = [b.detach().double().requires_grad_() for b in bs]
+    ln = torch.nn.functional.layer_norm
+    rn = ln(x2, (D,), w2[0], b2[0], 1e-5)
+    r0 = ln(torch.cat([q2[0], x2], 1), (D,), w2[1], b2[1], 1e-5)
+    r1 = ln(torch.cat([q2[1], x2], 1), (D,), w2[2], b2[2], 1e-5)
+    torch.autograd.backward([rn, r0, r1], [g.double() for g in gos])
+    tol = 2e-5 if out_dtype == F32 else 2e-2
+    for name, o, r in (("norm", n, rn), ("ln_1 layer 0", k0, r0), ("ln_1 layer 1", k1, r1)):
+        close(o.float(), r.float(), tol, tol, name)
+    close(x1.grad, x2.grad.float(), 1e-4, 1e-4, "dx")
+    for k in range(2):
+        close(q1[k].grad, q2[k].grad.float(), 1e-4, 1e-4, f"dq{k}")
+    for k in range(3):
+        close(w1[k].grad, w2[k].grad.float(), 1e-4, 1e-4 * (B * (G + T)) ** 0.5, f"dgamma{k}")
+        close(b1[k].grad, b2[k].grad.float(), 1e-4, 1e-4 * (B * (G + T)) ** 0.5, f"dbeta{k}")
+
+
+def test_three_affine_layernorm_reports_unsupported_widths():
+    """cols other than 768 / 1024: SEGCLIP_ERR_UNSUPPORTED, surfaced as None so the caller runs the single LayerNorms."""
+    x = rnd(6, 64, seed=141)
+    ws = [torch.ones(64, device=DEV) for _ in range(3)]
+    assert ops.layer_norm_multi(x, list(zip(ws, ws)), [None, None, None], 1e-5, F32) is None
