@@ -763,7 +763,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     static const int abl_env = segclip_ablation_env("SEGCLIP_ATTN_ABL");
     a.abl = abl_env;
     a.nitems = (int)(d->B * d->H);
-    if (smallq::covers(d) && d->colsum_part == nullptr) {
+    if (smallq::covers(d)) {
       hipLaunchKernelGGL(smallq::attn_smallq_bwd_kernel, dim3((unsigned)cdiv(a.nitems, smallq::WPB_BWD)), dim3(smallq::WPB_BWD * 64),
                          smallq::lds_bytes((int)d->Tk, true), stream, a, a.nitems);
       SEGCLIP_CHECK_LAUNCH("attn_smallq_bwd");

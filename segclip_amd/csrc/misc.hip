@@ -55,9 +55,32 @@ __global__ void act_fwd_kernel(const void* x, void* y, int64_t n, int act, int d
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     stx(y, dt, i, apply_act(act, ldx(x, dt, i)));
 }
+__device__ __forceinline__ f32x4 ld4x_any(const void* X, int dt, int64_t idx) {
+  if (dt == SEGCLIP_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + idx);
+  const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(X) + idx);
+  return f32x4{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16),
+               __uint_as_float(t[1] & 0xffff0000u)};
+}
 __global__ void act_bwd_kernel(const void* dy, const void* x, void* dx, int64_t n, int act, int dt) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     stx(dx, dt, i, ldx(dy, dt, i) * apply_act_grad(act, ldx(x, dt, i)));
+}
+// 4 elements per thread, 16-byte (fp32) / 8-byte (bf16) accesses; needs n % 4 == 0 and 16-byte aligned pointers
+__global__ void act_bwd_vec4_kernel(const void* __restrict__ dy, const void* __restrict__ x, void* __restrict__ dx, int64_t n4,
+                                    int act, int dt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 g = ld4x_any(dy, dt, i * 4), v = ld4x_any(x, dt, i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * apply_act_grad(act, v[j]);
+    if (dt == SEGCLIP_F32) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + i * 4) = o;
+    } else {
+      u32x2 t;
+      t[0] = pack2bf(o[0], o[1]); t[1] = pack2bf(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(dx) + i * 4) = t;
+    }
+  }
 }
 __global__ void scale_kernel(const float* x, const float* s, float* out, int64_t n) {
   const float sc = *s;
@@ -74,8 +97,8 @@ __global__ void reduce_sum_kernel(const float* x, float* out, int64_t n, float s
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
-// stage 1: block = 64 column-quads x 4 row lanes over one row chunk -> part[chunk][N]; stage 2 sums <=128 chunks.
-constexpr int CS_MAXCHUNK = 128;
+// stage 1: block = 64 column-quads x 4 row lanes over one row chunk -> part[chunk][N]; stage 2 sums <= CS_MAXCHUNK chunks.
+constexpr int CS_MAXCHUNK = 256;
 __device__ __forceinline__ f32x4 ld4x(const void* X, int dt, int64_t idx, bool vec, int nvalid) {
   f32x4 r = {0.f, 0.f, 0.f, 0.f};
   if (vec) {
@@ -118,8 +141,13 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
   for (int64_t k = 0; k < nchunk; ++k) s += part[k * N + c];
   out[c] = s;
 }
-static inline int64_t colsum_chunks(int64_t M) {
+// 256-row chunks for tall matrices; a short one (M = B*8 center rows) would leave each thread a 64-deep dependent load
+// chain on a handful of workgroups (22 us for 2048 x 3072 bf16), so chunks shrink to 32 rows until ~1024 workgroups exist
+static inline int64_t colsum_chunks(int64_t M, int64_t N) {
   int64_t c = cdiv(M, 256);
+  const int64_t colblocks = cdiv(N > 0 ? N : 1, 256);
+  const int64_t want = cdiv(1024, colblocks), most = cdiv(M, 32);
+  if (c < want) c = want < most ? want : most;
   return c < 1 ? 1 : (c > CS_MAXCHUNK ? CS_MAXCHUNK : c);
 }
 
@@ -563,7 +591,10 @@ extern "C" int segclip_act_fwd(const void* x, void* y, int64_t n, int act, int d
 }
 extern "C" int segclip_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dt, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, dy, x, dx, n, act, dt);
+  if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0)
+    hipLaunchKernelGGL(act_bwd_vec4_kernel, dim3(grid1d(n / 4)), dim3(TPB), 0, ST, dy, x, dx, n / 4, act, dt);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, dy, x, dx, n, act, dt);
   SEGCLIP_CHECK_LAUNCH("act_bwd");
   return 0;
 }
@@ -578,7 +609,7 @@ extern "C" int segclip_reduce_sum(const float* x, float* out, int64_t n, float s
   SEGCLIP_CHECK_LAUNCH("reduce_sum");
   return 0;
 }
-extern "C" size_t segclip_colsum_ws_bytes(int64_t M, int64_t N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
+extern "C" size_t segclip_colsum_ws_bytes(int64_t M, int64_t N) { return (size_t)colsum_chunks(M, N) * N * sizeof(float); }
 extern "C" int segclip_colsum(const void* X, float* out, void* ws, int64_t M, int64_t N, int64_t ld, int dt, void* stream) {
   SEGCLIP_REQUIRE(ws != nullptr, "colsum: workspace required");
   if (N == 0) return 0;
@@ -588,7 +619,7 @@ extern "C" int segclip_colsum(const void* X, float* out, void* ws, int64_t M, in
     SEGCLIP_CHECK_LAUNCH("colsum_rows");
     return 0;
   }
-  const int64_t nchunk = colsum_chunks(M);
+  const int64_t nchunk = colsum_chunks(M, N);
   const int64_t rows_per = cdiv(M > 0 ? M : 1, nchunk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(N, 256), (unsigned)nchunk), dim3(256), 0, ST, X, (float*)ws,
                      M, N, ld, dt, rows_per);

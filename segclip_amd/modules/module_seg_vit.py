@@ -93,9 +93,7 @@ class CrossAttentionBlock(nn.Module):
         else:
             kn = ops.layer_norm_cat(k, k_tail, self.ln_k.weight, self.ln_k.bias, self.ln_k.eps, ad)
         S = kn.shape[1]
-        qp = ops.linear(qn, w[:D], b[:D], act_dtype=ad).view(B * G, D)
-        kvp = ops.linear(kn, w[D:], b[D:], act_dtype=ad).view(B * S, 2 * D)
-        o = ops.CrossAttnFn.apply(qp, kvp, B, G, S, self.n_head, config.cross_mode).view(B, G, D)
+        o = ops.CrossInProjAttnFn.apply(qn, kn, w, b, B, G, S, self.n_head, config.cross_mode, ad).view(B, G, D)
         q = ops.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=q, out_dtype=torch.float32,
                        act_dtype=ad)
         z = self.ln_2(q)

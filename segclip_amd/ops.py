@@ -1122,6 +1122,67 @@ class CrossAttnFn(Function):
         return dq, dkv, None, None, None, None, None
 
 
+class CrossInProjAttnFn(Function):
+    """nn.MultiheadAttention of CrossAttentionBlock up to (not including) out_proj, with different query and key/value
+    inputs (modules/module_seg_vit.py:215): q = xq w[:D]^T + b[:D], [k | v] = xk w[D:]^T + b[D:], o = CrossAttnFn core.
+    One Function instead of two LinearFn on slices of in_proj_weight + CrossAttnFn: the weight gradient is ONE (3D, D)
+    buffer written by both wgrads (autograd's slice backward cost 4 zero fills + 4 copies + 2 adds per layer), the
+    bf16 weight comes from the parameter's shadow, and in bf16 mode the bias gradient is the attention backward's
+    per-sample token sums (no column-sum pass over the (B*S, 2D) gradient)."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, w, b, B, G, S, n_head, mode, act_dtype):
+        D = w.shape[1]
+        hd = D // n_head
+        xq, xk = xq.reshape(B * G, D), xk.reshape(B * S, D)
+        if xq.dtype != act_dtype:
+            xq = p_cast(xq, act_dtype)
+        if xk.dtype != act_dtype:
+            xk = p_cast(xk, act_dtype)
+        wc = wcast(w, act_dtype)
+        bd = b.detach()
+        qp = p_linear(xq, wc[:D], bd[:D])[0]
+        kv = p_linear(xk, wc[D:], bd[D:])[0]
+        o = torch.empty_like(qp)
+        ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
+        ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd),
+                        False, 0, 0, D)
+        stats = p_attn_fwd(ad, qp)
+        ctx.save_for_backward(xq, xk, wc, qp, kv, o, stats)
+        ctx.cfg = (B, G, S, n_head, mode)
+        ctx.gslot = _slot_of(w)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        xq, xk, wc, qp, kv, o, stats = ctx.saved_tensors
+        B, G, S, n_head, mode = ctx.cfg
+        D = qp.shape[1]
+        hd = D // n_head
+        do = do.contiguous()
+        ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
+        ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd),
+                        False, 0, 0, D)
+        dq = torch.empty_like(qp)
+        dkv = torch.empty_like(kv)
+        part = _empty((B, 3 * D), torch.float32, do) if qp.dtype == torch.bfloat16 else None
+        p_attn_bwd(ad, stats, do, dq, dkv, dkv, (G * D, D), ks, ks, (G * D, D), 0, 0, D, colsum_part=part)
+        dxq = p_dgrad(dq, wc[:D], xq.dtype)
+        dxk = p_dgrad(dkv, wc[D:], xk.dtype)
+        dw = _slot_out(ctx.gslot, (3 * D, D))
+        if dw is None:
+            dw = _empty((3 * D, D), torch.float32, do)
+        p_wgrad(dq, xq, out=dw[:D])
+        p_wgrad(dkv, xk, out=dw[D:])
+        if part is not None:
+            db = p_colsum(part)
+        else:
+            db = _empty((3 * D,), torch.float32, do)
+            p_colsum(dq, out=db[:D])
+            p_colsum(dkv, out=db[D:])
+        return dxq.view(B, G, D), dxk.view(B, S, D), dw, db, None, None, None, None, None, None
+
+
 class PatchEmbedFn(Function):
     """conv1 (16x16/16, no bias) as im2col + GEMM with the positional table fused as the epilogue
     residual (modules/module_clip_vtransformer.py:56-64).  The CLS row the reference prepends is

@@ -969,3 +969,39 @@ def test_three_affine_layernorm_reports_unsupported_widths():
     x = rnd(6, 64, seed=141)
     ws = [torch.ones(64, device=DEV) for _ in range(3)]
     assert ops.layer_norm_multi(x, list(zip(ws, ws)), [None, None, None], 1e-5, F32) is None
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("mode", ["t18", "intended"])
+@pytest.mark.parametrize("B,G,T,H", [(4, 8, 196, 12), (3, 8, 48, 2)])
+def test_cross_attention_with_its_input_projections(dtype, mode, B, G, T, H):
+    """ops.CrossInProjAttnFn (q / kv projections of nn.MultiheadAttention with different inputs + the cross-attention core,
+    modules/module_seg_vit.py:215) against the same composition in torch fp32: output, both input gradients, the ONE
+    in_proj weight gradient written by two wgrads, and the bias gradient - in bf16 mode taken from the attention backward's
+    token sums (sum_key dV = sum_q dO, sum_key dK = 0)."""
+    D, S = H * 64, G + T
+    xq, xk = rnd(B, G, D, dtype=dtype, seed=151), rnd(B, S, D, dtype=dtype, seed=152)
+    w, b = rnd(3 * D, D, seed=153, scale=D ** -0.5), rnd(3 * D, seed=154, scale=0.1)
+    do = rnd(B * G, D, dtype=dtype, seed=155)
+    t1 = [t.detach().clone().requires_grad_() for t in (xq, xk, w, b)]
+    o = ops.CrossInProjAttnFn.apply(t1[0], t1[1], t1[2], t1[3], B, G, S, H, mode, dtype)
+    o.backward(do)
+    wr = w.to(dtype).float() if dtype == BF else w           # the kernels see the bf16 shadow of the weight
+    t2 = [t.detach().float().requires_grad_() for t in (xq, xk, wr, b)]
+    qp = (t2[0].reshape(B * G, D) @ t2[2][:D].T + t2[3][:D]).view(B, G, D)
+    kvp = t2[1].reshape(B * S, D) @ t2[2][D:].T + t2[3][D:]
+    k3, v3 = kvp[:, :D], kvp[:, D:]
+    if mode == "t18":
+        k3, v3 = k3.reshape(S, B, D).permute(1, 0, 2), v3.reshape(S, B, D).permute(1, 0, 2)
+    else:
+        k3, v3 = k3.reshape(B, S, D), v3.reshape(B, S, D)
+    ref = _attn_ref(qp, k3, v3, H, False)
+    ref.backward(do.float().view(B, G, D))
+    rt, at = (2e-4, 2e-4) if dtype == F32 else (3e-2, 3e-2)
+    close(o.view(B, G, D), ref, rt, at, "o")
+    close(t1[0].grad, t2[0].grad, rt, at, "dxq")
+    close(t1[1].grad, t2[1].grad, rt, at, "dxk")
+    scale = float(t2[2].grad.abs().max())
+    close(t1[2].grad, t2[2].grad, rt, at * max(scale, 1.0), "dw (3D, D)")
+    close(t1[3].grad, t2[3].grad, rt, at * max(float(t2[3].grad.abs().max()), 1.0), "db (3D)")
+    assert float(t2[3].grad[D:2 * D].abs().max()) <= 1e-3 * max(float(t2[3].grad.abs().max()), 1.0)   # the K bias gradient is ~0

@@ -27,3 +27,14 @@ tot = sum(r[2] for r in rows)
 print(f"total kernel time per pass {tot / 3 / 1e3:.3f} ms over {sum(r[1] for r in rows) / 3:.0f} launches")
 for k, c, t in rows[:40]:
     print(f"{t / 3:9.1f} us/pass  {c / 3:5.1f}x  {k[:110]}")
+if os.environ.get("DETAIL"):
+    # launch order of the LAST pass with per-kernel duration and the idle gap before it
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    evs.sort(key=lambda e: e.time_range.start)
+    n = len(evs) // 3
+    last = evs[2 * n:]
+    prev_end = last[0].time_range.start
+    print(f"--- last pass: {len(last)} launches, span {(last[-1].time_range.end - last[0].time_range.start) / 1e3:.3f} ms")
+    for e in last:
+        print(f"{e.time_range.end - e.time_range.start:8.1f} us  gap {e.time_range.start - prev_end:7.1f}  {e.name[:100]}")
+        prev_end = e.time_range.end
