@@ -710,12 +710,16 @@ class LinearFn(Function):
             du = torch.empty_like(dy)
             L.check(L.load().segclip_act_bwd(L.ptr(dy), L.ptr(aux), L.ptr(du), dy.numel(), ctx.act, L.dt(dy),
                                              L.stream()), "act_bwd")
+        db = p_colsum(du) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        if du.dtype == torch.float32 and x.dtype == torch.bfloat16:
+            # an fp32 output gradient (fp32 residual stream) of a bf16 Linear: the GEMMs round it to bf16 while staging
+            # anyway, but an fp32 operand keeps them off the LDS-DMA kernels - round once here (same values)
+            du = p_cast(du, torch.bfloat16)
         dx = p_dgrad(du, wc, x.dtype, w_kn=ctx.w_kn) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             shp = (x.shape[1], du.shape[1]) if ctx.w_kn else (du.shape[1], x.shape[1])
             dw = p_wgrad(du, x, w_kn=ctx.w_kn, out=_slot_out(ctx.gslot, shp))
-        db = p_colsum(du) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None
 
