@@ -269,7 +269,7 @@ def roofline_block(a, step, pairs_per_gpu, world, work, collective_free=True):
         if extra in cl:
             classes[extra] = {"time_per_step_ms": cl[extra]["time_per_step_ms"], "launches_per_step": cl[extra]["launches_per_step"]}
     tr = m["traffic"]
-    return {"bound": "mfma", "kernel": "gemm_bf16_pq_kernel / gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback), all launches of a step",
+    return {"bound": "mfma", "kernel": "gemm_bf16_pq_kernel / gemm_bf16_pq_group_kernel / gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback), all launches of a step",
             "achieved": g["achieved"], "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": g["frac"],
             "avg_launch_us": g["avg_launch_us"], "launches_per_step": g["launches_per_step"],
             "time_per_step_ms": g["time_per_step_ms"],

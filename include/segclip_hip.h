@@ -458,6 +458,33 @@ int segclip_adamw_step(const segclip_adamw_tensor* tensors, int64_t count, const
 int segclip_train_step_finish(segclip_train_ctrl* ctrl, const float* loss, float* logit_scale, float clamp_max,
                               void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Grouped weight gradients (bf16 operands, fp32 results):  dw_i (M_i, N_i) = dy_i^T x_i  for n problems over the SAME R token
+ * rows, as ONE launch.  The four nn.Linear weight gradients of a residual block (modules/module_seg_vit.py:162-196: in_proj,
+ * out_proj, c_fc, c_proj; the text blocks of modules/module_clip_ttransformer.py:20-37) have 9-36 output tiles each: launched
+ * one by one, each needs 7-28 K ranges to fill the 256 CUs and leaves 64 MB of fp32 partial tiles to be combined; the gradients
+ * of several consecutive blocks together fill the chip with 1-4 K ranges.
+ *   segclip_wgrad_group_splits(tiles, ksteps): the K-range count the library recommends for a group with `tiles` 256x256
+ *       output tiles in total over ksteps = R / 64 steps.
+ *   splits == 1: results go to dw_i (row pitch ld_dw).  splits > 1: K range s of problem i is left, raw, at
+ *       ws + (sum_{j<i} splits*M_j*N_j + s*M_i*N_i) floats; the caller sums the ranges in order (segclip_reduce_multi, kind 0).
+ *   Not covered (SEGCLIP_ERR_UNSUPPORTED, nothing launched): M_i or N_i not multiples of 256, R not a multiple of 64, operands
+ *       off 16-byte boundaries, leading dimensions not multiples of 8, n > 48.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct segclip_wgrad_item {
+  const void* dy;   /* (R, M) bf16, row pitch ld_dy */
+  const void* x;    /* (R, N) bf16, row pitch ld_x  */
+  float* dw;        /* (M, N) fp32, row pitch ld_dw (written when splits == 1) */
+  int64_t M, N, ld_dy, ld_x, ld_dw;
+} segclip_wgrad_item;
+int segclip_wgrad_group_splits(int64_t tiles, int64_t ksteps);
+/* the time model behind that choice (microseconds on MI355X: rounds of 256 workgroups x (K loop + output) + the partial tiles
+ * written and read back); callers use it to decide how many blocks to group */
+double segclip_wgrad_group_model_us(int64_t tiles, int64_t ksteps, int splits);
+size_t segclip_wgrad_group_ws_bytes(const segclip_wgrad_item* items, int n, int splits);
+int segclip_wgrad_group(const segclip_wgrad_item* items, int n, int64_t R, int splits, void* ws, size_t ws_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ class ReduceEntry(C.Structure):
                 ("scale", f32), ("out_dtype", i32)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("M", i64), ("N", i64), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64)]
+
+
 class TrainCtrl(C.Structure):
     _fields_ = [("grad_sqnorm", f32), ("clip_coef", f32), ("nan_skips", i32), ("steps", i32),
                 ("loss_sum", f32), ("last_loss", f32), ("reserved", i32 * 2)]
@@ -75,6 +79,10 @@ SIGNATURES = {
     "segclip_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),
     "segclip_layernorm_bwd_ws_bytes": (C.c_size_t, [i64, i64]),
     "segclip_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "segclip_wgrad_group_splits": (C.c_int, [i64, i64]),
+    "segclip_wgrad_group_model_us": (C.c_double, [i64, i64, C.c_int]),
+    "segclip_wgrad_group_ws_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
+    "segclip_wgrad_group": (C.c_int, [vp, C.c_int, i64, C.c_int, vp, C.c_size_t, vp]),
     "segclip_layernorm_fwd_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),
     "segclip_layernorm_bwd_multi_ws_bytes": (C.c_size_t, [i64, i64, C.c_int]),
     "segclip_layernorm_bwd_multi": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, vp]),

@@ -17,6 +17,12 @@ text_after_blocks : with overlap_towers: the text tower is enqueued after this m
                 0 = before the vision tower).  The host needs ~3 ms to enqueue the text tower: queued first, the vision
                 stream idles that long at the start of every step, and - autograd replays the recording order backwards -
                 again ~6 ms at the end of the backward pass (tools/stream_gaps.py)
+wgrad_group_blocks : bf16 mode, inside ResStackFn: the weight gradients of up to this many consecutive blocks run as ONE grouped
+                launch (ops.WgradGroup / segclip_wgrad_group) with few K ranges instead of 4 launches per block with 7-28 K
+                ranges each (64 MB of fp32 partial tiles per gradient); the partition of a stack into groups minimises the
+                library's time model.  1 = one launch per gradient (the round-3 behaviour).  Env SEGCLIP_WGRAD_GROUP.
+wgrad_group_blocks_dist : the same limit while GradSync bucket slots are active (world size > 1): short groups, so that
+                the bucket exchanges keep overlapping with the backward pass
 trust_weight_shadows : False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
                 True: only weights whose autograd version changed (set per model by train.prep_optimizer when the
                 fused optimizer maintains the bf16 copies itself)
@@ -54,7 +60,8 @@ import torch
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
-                 text_after_blocks=4)
+                 text_after_blocks=4,
+                 wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=3)
 _tls = threading.local()
 
 

@@ -68,6 +68,18 @@ struct PQArgs {
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
+// Grouped weight gradients (PQ_SLAB): several C_p = A_p^T B_p problems with the same K (token rows) and the same number of K
+// ranges run as ONE launch - the (K range, tile) units of problem p are [unit_end[p-1], unit_end[p]).  A residual block has four
+// weight gradients of 9-36 tiles each: launched one by one every one of them needs 7-28 K ranges to fill the 256 CUs (64 MB
+// of fp32 partial tiles written and read back per gradient); the gradients of several blocks together fill the chip with 1-4.
+struct PQProb {
+  const bf16_t* A; const bf16_t* B; float* Cf;
+  int64_t slab_stride;
+  int lda, ldb, ldc, nbx, ntiles, unit_end;
+};
+constexpr int PQ_GROUP_MAX = 48;
+struct PQGroup { int nprob; int pad; PQProb prob[PQ_GROUP_MAX]; };
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -469,8 +481,9 @@ __device__ __forceinline__ void pq_res32_issue(const PQArgs& g, int lane, int wa
   for (int k = 0; k < 8; ++k) res[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rq + (int64_t)(Q * 8 + k) * 2 * g.lds));
 }
 
+// unit_given >= 0 (grouped launch): this workgroup's unit inside the problem described by g
 template <bool A_KS, bool B_KS, int MODE>
-__global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
+__device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -484,6 +497,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
   // PQ_SLAB (split-K): the (K range, tile) units are ordered K-range-major, so that the tiles of ONE K range - which share
   // its operand rows - sit behind one L2
   int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  if (MODE == PQ_SLAB && unit_given >= 0) unit = unit_given;
   // tail split: workgroups nfull .. are the K ranges of the tail tiles; the tail_S ranges of a tile share bid & 7 (one XCD)
   const bool has_tail = MODE != PQ_SLAB && g.tail_S > 1;
   bool tail = false;
@@ -762,6 +776,26 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
 #undef PQ_HALF
 }
 
+template <bool A_KS, bool B_KS, int MODE>
+__global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_kernel(PQArgs g) {
+  pq_main<A_KS, B_KS, MODE>(g, -1);
+}
+
+// grouped weight gradients: the XCD-chunked unit sequence runs over ALL problems (a chunk = a few K ranges of a few problems)
+__global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_group_kernel(PQArgs g, PQGroup grp) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int p = 0;
+  while (p + 1 < grp.nprob && unit >= grp.prob[p].unit_end) ++p;
+  const int u0 = p ? grp.prob[p - 1].unit_end : 0;
+  g.A = grp.prob[p].A; g.B = grp.prob[p].B; g.Cf = grp.prob[p].Cf;
+  g.slab_stride = grp.prob[p].slab_stride;
+  g.lda = grp.prob[p].lda; g.ldb = grp.prob[p].ldb; g.ldc = grp.prob[p].ldc;
+  g.nbx = grp.prob[p].nbx; g.ntiles = grp.prob[p].ntiles;
+  pq_main<true, true, PQ_SLAB>(g, unit - u0);
+}
+
 }  // namespace
 
 // The file is compiled once per PQ_PART (build.sh): 0 = forward layout, 1 = data-gradient layout, 2 = host dispatcher,
@@ -789,6 +823,11 @@ void segclip_pq_launch_w(int mode, dim3 grid, hipStream_t stream, const void* ar
   const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
   (void)mode;
   PQ_LAUNCH(true, true, PQ_SLAB);
+}
+void segclip_pq_launch_group(dim3 grid, hipStream_t stream, const void* args, const void* group) {
+  const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
+  const PQGroup grp = *reinterpret_cast<const PQGroup*>(group);
+  hipLaunchKernelGGL(gemm_bf16_pq_group_kernel, grid, dim3(NWV * 64), 0, stream, g, grp);
 }
 #endif
 
@@ -930,5 +969,76 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   if (!pq_tail_setup(g, d, stream, &nwg)) return false;
   (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3(nwg), stream, &g);
   return true;
+}
+void segclip_pq_launch_group(dim3, hipStream_t, const void*, const void*);
+
+// K ranges for a group of `tiles` 256x256 output tiles over `ksteps` 64-row K steps: the count that minimises the modelled time
+//   ceil(tiles * s / 256) rounds x (K loop of ksteps / s steps at ~1.26 us + ~5 us of prologue / output) + the fp32 partial tiles
+//   written and read back when s > 1 (~0.075 us each, device-wide)
+extern "C" double segclip_wgrad_group_model_us(int64_t tiles, int64_t ksteps, int splits) {
+  if (tiles < 1 || ksteps < 1 || splits < 1) return 0.0;
+  const int64_t per = cdiv(ksteps, splits);
+  const double rounds = (double)cdiv(tiles * splits, 256);
+  return rounds * (per * 1.26 + 5.0) + (splits > 1 ? tiles * splits * 0.075 : 0.0);
+}
+extern "C" int segclip_wgrad_group_splits(int64_t tiles, int64_t ksteps) {
+  if (tiles < 1 || ksteps < 1) return 1;
+  int best = 1;
+  double bt = 0.0;
+  for (int s = 1; s <= 32 && (s == 1 || s <= ksteps / 8); ++s) {
+    if ((s - 1) * cdiv(ksteps, s) >= ksteps) continue;        // an empty last range
+    const double t = segclip_wgrad_group_model_us(tiles, ksteps, s);
+    if (s == 1 || t < bt) { bt = t; best = s; }
+  }
+  return best;
+}
+extern "C" size_t segclip_wgrad_group_ws_bytes(const segclip_wgrad_item* it, int n, int splits) {
+  if (splits <= 1) return 0;
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += (size_t)splits * it[i].M * it[i].N * sizeof(float);
+  return total;
+}
+// dw_i (M_i, N_i) fp32 = dy_i^T x_i for n problems over the same R token rows, as one launch of the weight-gradient kernel.
+// splits == 1: written to dw_i directly.  splits > 1: K range s of problem i is left as a raw partial tile set at
+// ws + (sum_{j<i} splits*M_j*N_j + s*M_i*N_i) floats and the CALLER combines them (segclip_reduce_multi, kind slabs) - the
+// order of the partial sums is fixed, so results are reproducible.  SEGCLIP_ERR_UNSUPPORTED (nothing launched) unless every
+// problem has bf16 operands on 16-byte boundaries, M_i and N_i multiples of 256 and leading dimensions multiples of 8.
+extern "C" int segclip_wgrad_group(const segclip_wgrad_item* it, int n, int64_t R, int splits, void* ws, size_t ws_bytes,
+                                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 1 || n > PQ_GROUP_MAX || R % BK != 0 || R < BK || splits < 1) { segclip_set_error("wgrad_group: unsupported group"); return SEGCLIP_ERR_UNSUPPORTED; }
+  const int64_t per = cdiv(R / BK, splits) * BK;
+  if ((int64_t)(splits - 1) * per >= R) { segclip_set_error("wgrad_group: empty K range"); return SEGCLIP_ERR_UNSUPPORTED; }
+  if (splits > 1 && (ws == nullptr || ws_bytes < segclip_wgrad_group_ws_bytes(it, n, splits) || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)) {
+    segclip_set_error("wgrad_group: workspace too small");
+    return SEGCLIP_ERR_INVALID;
+  }
+  PQGroup grp = {};
+  grp.nprob = n;
+  int64_t units = 0;
+  float* slab = reinterpret_cast<float*>(ws);
+  for (int i = 0; i < n; ++i) {
+    const segclip_wgrad_item& q = it[i];
+    const bool ok = q.M > 0 && q.N > 0 && q.M % BT == 0 && q.N % BT == 0 && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(q.dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 &&
+                    64 * q.ld_dy * 2 < (int64_t)1 << 31 && 64 * q.ld_x * 2 < (int64_t)1 << 31 &&
+                    (splits > 1 || (q.dw != nullptr && q.ld_dw % 4 == 0 && (reinterpret_cast<uintptr_t>(q.dw) & 15) == 0 &&
+                                    256 * q.ld_dw * 4 < (int64_t)1 << 31));
+    if (!ok) { segclip_set_error("wgrad_group: problem %d is not covered (256-multiples, 16-byte alignment)", i); return SEGCLIP_ERR_UNSUPPORTED; }
+    PQProb& p = grp.prob[i];
+    p.A = reinterpret_cast<const bf16_t*>(q.dy); p.B = reinterpret_cast<const bf16_t*>(q.x);
+    p.lda = (int)q.ld_dy; p.ldb = (int)q.ld_x;
+    p.nbx = (int)(q.N / BT); p.ntiles = (int)((q.M / BT) * (q.N / BT));
+    if (splits > 1) { p.Cf = slab; p.ldc = (int)q.N; p.slab_stride = q.M * q.N; slab += (int64_t)splits * q.M * q.N; }
+    else { p.Cf = q.dw; p.ldc = (int)q.ld_dw; p.slab_stride = 0; }
+    units += (int64_t)p.ntiles * splits;
+    p.unit_end = (int)units;
+  }
+  PQArgs g = {};
+  g.K = (int)R; g.kper = per;
+  g.abl = 0;
+  segclip_pq_launch_group(dim3((unsigned)units), stream, &g, &grp);
+  SEGCLIP_CHECK_LAUNCH("wgrad_group");
+  return 0;
 }
 #endif  // PQ_PART == 2

@@ -112,6 +112,79 @@ class ReduceQueue:
         self.slabs, self.rows, self.keep = [], [], []
 
 
+class WgradGroup:
+    """Weight gradients dw = dy^T x of several consecutive residual blocks, collected and run as ONE launch of the
+    weight-gradient kernel (segclip_wgrad_group).  A block's four gradients have 9-36 output tiles each; one by one, each is
+    cut into 7-28 K ranges to fill the 256 CUs and leaves 64 MB of fp32 partial tiles to combine; grouped, the chip is full
+    with 1-4 K ranges (7 vision blocks: none).  The operands stay referenced until flush(); add() hands out the result
+    tensor, which is valid once flush() has been enqueued."""
+
+    def __init__(self):
+        self.items = []
+
+    @staticmethod
+    def covers(dy, x, out):
+        return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and x.dim() == 2
+                and dy.shape[0] == x.shape[0] and dy.shape[0] % 64 == 0 and dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0
+                and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+                and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+                and (out is None or (out.is_contiguous() and out.data_ptr() % 16 == 0)))
+
+    def add(self, dy, x, out=None):
+        if not self.covers(dy, x, out) or (self.items and self.items[0][0].shape[0] != dy.shape[0]) or len(self.items) >= 48:
+            return p_wgrad(dy, x, out=out)
+        dw = out if out is not None else _empty((dy.shape[1], x.shape[1]), torch.float32, dy)
+        self.items.append((dy, x, dw))
+        return dw
+
+    def flush(self):
+        if not self.items:
+            return
+        lib = L.load()
+        items, self.items = self.items, []
+        R = items[0][0].shape[0]
+        arr = (L.WgradItem * len(items))()
+        tiles = 0
+        for a, (dy, x, dw) in zip(arr, items):
+            a.dy, a.x, a.dw = L.ptr(dy), L.ptr(x), L.ptr(dw)
+            a.M, a.N, a.ld_dy, a.ld_x, a.ld_dw = dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.stride(0)
+            tiles += (dy.shape[1] // 256) * (x.shape[1] // 256)
+        splits = lib.segclip_wgrad_group_splits(tiles, R // 64)
+        nbytes = lib.segclip_wgrad_group_ws_bytes(arr, len(items), splits)
+        ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=items[0][0].device)
+        if _OpCount.enabled:
+            for dy, x, dw in items:
+                _OpCount.add("gemm_bf16", 2.0 * R * dy.shape[1] * x.shape[1], 2 * R * (dy.shape[1] + x.shape[1]) + 4 * dw.numel())
+        try:
+            L.check(lib.segclip_wgrad_group(arr, len(items), R, splits, L.ptr(ws), nbytes, L.stream()), "wgrad_group")
+        except L.Unsupported:
+            for dy, x, dw in items:
+                p_wgrad(dy, x, out=dw)
+            return
+        if splits > 1:
+            rq, off = ReduceQueue(), 0
+            for dy, x, dw in items:
+                n = dw.numel()
+                rq.add_slabs(ws[off:off + splits * n], dw, splits, n, 1.0)
+                off += splits * n
+            rq.flush()
+
+
+def wgrad_group_plan(nblk, tiles_blk, ksteps, gmax):
+    """Sizes (in blocks, in backward order) of the weight-gradient groups of a stack of nblk equal blocks: the partition with
+    the smallest modelled time (segclip_wgrad_group_model_us at the K-range count the library would choose)."""
+    lib = L.load()
+    gmax = max(1, min(int(gmax), nblk, 48 // 4))
+    cost = [0.0] * (gmax + 1)
+    for n in range(1, gmax + 1):
+        s = lib.segclip_wgrad_group_splits(tiles_blk * n, ksteps)
+        cost[n] = lib.segclip_wgrad_group_model_us(tiles_blk * n, ksteps, s)
+    best = [(0.0, [])] + [None] * nblk
+    for k in range(1, nblk + 1):
+        best[k] = min(((best[k - n][0] + cost[n], best[k - n][1] + [n]) for n in range(1, min(gmax, k) + 1)), key=lambda t: t[0])
+    return best[nblk][1]
+
+
 _PQ_TAIL_ENV = os.environ.get("SEGCLIP_PQ_TAIL", "0") not in ("", "0")
 
 
@@ -847,7 +920,8 @@ def _aux_kind(act_dtype, act, M=0, N=0):
     return 0
 
 
-def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None, reduce_side=None):
+def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None, reduce_side=None,
+                  wgroup=None):
     """Hand-scheduled backward of one block.  g: fp32 (M, D) gradient of the block output or None; g16: its bf16 copy or
     None.  need[i]: gradient wanted for forward input i (0 = x, 1..12 = the parameters in forward order).
     chain=False: fp32 residual gradient in and out (plus the bf16 copy the LayerNorm backward emits for free).
@@ -889,14 +963,22 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     # the block's trailing reductions (split-K combines, LayerNorm / bias column sums) are queued and flushed as two
     # launches at the end of the block (not when the weight gradients run on the side stream)
     rq = ReduceQueue() if side is None else None
+    if side is not None:
+        wgroup = None
+
+    def wgrad(dy_, x_, out_):
+        # wgroup (ResStackFn): the weight gradients of several blocks run later, as one grouped launch (WgradGroup)
+        if wgroup is not None:
+            return wgroup.add(dy_, x_, out_)
+        return on_side(lambda: p_wgrad(dy_, x_, out=out_, defer=rq))
     # ---- MLP
     du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
                        colsum_out=_slot_out(s_bfc, (F4,)) if need[10] else None,
                        aux_kind=2 if u.dtype == torch.uint8 else _aux_kind(act_dtype, act),
                        defer=rq, pitched=bf)  # (dy c_proj)*act'(u), colsum
-    dwpr = on_side(lambda: p_wgrad(g16, h, out=_slot_out(sp, (D, F4)), defer=rq)) if need[11] else None
+    dwpr = wgrad(g16, h, _slot_out(sp, (D, F4))) if need[11] else None
     dy2 = p_dgrad(du, wfc_c, act_dtype)
-    dwfc = on_side(lambda: p_wgrad(du, y2, out=_slot_out(sf, (F4, D)), defer=rq)) if need[9] else None
+    dwfc = wgrad(du, y2, _slot_out(sf, (F4, D))) if need[9] else None
     two = bf and not chain   # fp32 dx + its bf16 copy
     r = p_ln_bwd(dy2, x1, ln2w, mean2, rstd2, dres=res_in, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
                  outs=(_slot_out(s_ln2w, (D,)) if need[7] else None, _slot_out(s_ln2b, (D,)) if need[8] else None,
@@ -906,7 +988,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     dbpr = r[-1] if need[12] else None                           # colsum(g), fused into the LN2 backward
     # ---- attention
     do = p_dgrad(dx1_16, wo_c, act_dtype)
-    dwo = on_side(lambda: p_wgrad(dx1_16, o, out=_slot_out(so, (D, D)), defer=rq)) if need[5] else None
+    dwo = wgrad(dx1_16, o, _slot_out(so, (D, D))) if need[5] else None
     dqkv = _empty((M, 3 * D), act_dtype, x2)
     s3 = (T * 3 * D, 3 * D)
     ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
@@ -914,7 +996,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     part = _empty((B, 3 * D), torch.float32, x2) if (bf and need[4]) else None  # in_proj bias gradient per sample
     p_attn_bwd(ad, stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=part)
     dy1 = p_dgrad(dqkv, wqkv_c, act_dtype)
-    dwqkv = on_side(lambda: p_wgrad(dqkv, y1, out=_slot_out(sq, (3 * D, D)), defer=rq)) if need[3] else None
+    dwqkv = wgrad(dqkv, y1, _slot_out(sq, (3 * D, D))) if need[3] else None
     dbqkv = None
     if need[4]:
         bq_out = _slot_out(s_bqkv, (3 * D,))
@@ -1017,6 +1099,7 @@ class ResStackFn(Function):
         ctx.klen, ctx.nblk = klen, nblk
         ctx.chain = (bool(chain) or resid16) and act_dtype == torch.bfloat16
         ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
+        ctx.wgrad_group, ctx.wgrad_group_dist = int(_cfg.wgrad_group_blocks), int(_cfg.wgrad_group_blocks_dist)
         ctx.params = params
         ctx.slots = tuple(_slot_of(w) for w in params)
         if resid16 and not keep16:
@@ -1047,6 +1130,19 @@ class ResStackFn(Function):
         # against the stream that PRODUCED a gradient, which must then be this one)
         from . import config as _cfg
         rside = _reduce_stream() if (_cfg.reduce_side and not ctx.overlap_wgrad and all(s is None for s in ctx.slots)) else None
+        # config.wgrad_group_blocks (captured at forward time): the weight gradients of up to that many consecutive blocks run
+        # as one grouped launch (WgradGroup); with GradSync slots the groups stay short so that the bucket exchanges keep
+        # overlapping with the backward pass.  A block's gradients are published when its group has been enqueued.
+        wg, sizes = None, []
+        if ctx.wgrad_group > 1 and ctx.cfg[-1] == torch.bfloat16 and not ctx.overlap_wgrad and nblk > 1:
+            Dm, F4 = ctx.params[2].shape[1], ctx.params[8].shape[0]
+            if Dm % 256 == 0 and F4 % 256 == 0 and (B * T) % 64 == 0:
+                gmax = ctx.wgrad_group if all(s is None for s in ctx.slots) else min(ctx.wgrad_group, ctx.wgrad_group_dist)
+                tiles_blk = (4 * Dm * Dm + 2 * F4 * Dm) // 65536
+                sizes = wgrad_group_plan(nblk, tiles_blk, (B * T) // 64, gmax)
+                wg = WgradGroup() if max(sizes) > 1 else None
+        left = sizes.pop(0) if wg is not None else 0
+        pending = []
         for b in reversed(range(nblk)):
             P = ctx.params[b * 12:(b + 1) * 12]
             sl = ctx.slots[b * 12:(b + 1) * 12]
@@ -1054,17 +1150,26 @@ class ResStackFn(Function):
             gslots = (sl[2], sl[4], sl[8], sl[10])
             vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
             cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
-                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep, rside)
-            for i, (p, gr, slot) in enumerate(zip(P, grads, sl)):
-                if gr is None:
+                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep, rside, wg)
+            pending.append((b, P, sl, grads))
+            if wg is not None:
+                left -= 1
+                if left > 0 and b > 0:
                     continue
-                owner = slot.owner() if slot is not None else None
-                if owner is not None and gr.data_ptr() == slot.ptr and p.grad is None and slot.single_use():
-                    # zero-copy gradient inside its all-reduce bucket: publish it now (autograd gets None for it)
-                    p.grad = gr
-                    owner._on_grad(p)
-                else:
-                    out[b * 12 + i] = gr
+                wg.flush()
+                left = sizes.pop(0) if sizes else nblk
+            for b_, P_, sl_, grads_ in pending:
+                for i, (p, gr, slot) in enumerate(zip(P_, grads_, sl_)):
+                    if gr is None:
+                        continue
+                    owner = slot.owner() if slot is not None else None
+                    if owner is not None and gr.data_ptr() == slot.ptr and p.grad is None and slot.single_use():
+                        # zero-copy gradient inside its all-reduce bucket: publish it now (autograd gets None for it)
+                        p.grad = gr
+                        owner._on_grad(p)
+                    else:
+                        out[b_ * 12 + i] = gr
+            pending = []
         if keep is not None:
             torch.cuda.current_stream().wait_stream(_wgrad_stream())
             keep.clear()

@@ -1005,3 +1005,81 @@ def test_cross_attention_with_its_input_projections(dtype, mode, B, G, T, H):
     close(t1[2].grad, t2[2].grad, rt, at * max(scale, 1.0), "dw (3D, D)")
     close(t1[3].grad, t2[3].grad, rt, at * max(float(t2[3].grad.abs().max()), 1.0), "db (3D)")
     assert float(t2[3].grad[D:2 * D].abs().max()) <= 1e-3 * max(float(t2[3].grad.abs().max()), 1.0)   # the K bias gradient is ~0
+
+
+@pytest.mark.parametrize("R,shapes,pitched", [
+    (6272, [(768, 256), (256, 256), (512, 768)], False),                      # few tiles: K ranges, partial tiles combined
+    (19712, [(1536, 512), (512, 512), (2048, 512), (512, 2048)] * 3, True),    # three text blocks, pitched MLP operands
+    (1024, [(2048, 2048)] * 4, False),                                         # 256 tiles over 16 K steps: one range, direct write
+])
+def test_grouped_weight_gradients(R, shapes, pitched):
+    """ops.WgradGroup / segclip_wgrad_group (the weight gradients of several residual blocks as ONE launch with few K
+    ranges; reference layers modules/module_seg_vit.py:162-196) against dy^T x in fp64, and run-to-run bit-reproducible."""
+    lib_items = []
+    for i, (M, N) in enumerate(shapes):
+        dy, x = rnd(R, M, dtype=BF, seed=200 + 2 * i, scale=0.5), rnd(R, N, dtype=BF, seed=201 + 2 * i, scale=0.5)
+        if pitched and M >= 2048:      # row pitch of the MLP hidden tensors (ops._empty_pitched)
+            buf = torch.zeros(R, M + 512, dtype=BF, device=DEV)
+            buf[:, :M] = dy
+            dy = buf[:, :M]
+        lib_items.append((dy, x))
+
+    def run():
+        wg = ops.WgradGroup()
+        outs = [wg.add(dy, x) for dy, x in lib_items]
+        assert len(wg.items) == len(shapes), "every problem here is expected to join the group"
+        wg.flush()
+        torch.cuda.synchronize()
+        return outs
+    o1, o2 = run(), run()
+    for (dy, x), a, b in zip(lib_items, o1, o2):
+        ref = (dy.double().t() @ x.double()).float()
+        close(a, ref, 2e-3, 2e-3 * float(ref.abs().max()), f"dw {tuple(a.shape)}")
+        assert torch.equal(a, b), "grouped weight gradients must be reproducible"
+    # a problem the kernel does not cover (128 columns) runs on its own and is still correct
+    wg = ops.WgradGroup()
+    dy, x = rnd(R, 128, dtype=BF, seed=231), rnd(R, 256, dtype=BF, seed=232)
+    dw = wg.add(dy, x)
+    assert not wg.items
+    close(dw, (dy.double().t() @ x.double()).float(), 2e-3, 2e-2, "uncovered problem")
+
+
+def test_res_stack_grouped_weight_gradients_match_per_block():
+    """ResStackFn with config.wgrad_group_blocks = 12 (grouped launches) against = 1 (one launch per gradient): the same
+    partial products in a different K-range partition - every parameter gradient within fp32 summation noise, dx bit-equal
+    (the data-gradient chain does not change)."""
+    import segclip_amd
+    B, T, D, H, nblk = 4, 64, 256, 4, 5
+    g = torch.Generator().manual_seed(13)
+    blocks = []
+    for _ in range(nblk):
+        P = [torch.ones(D) + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g),
+             torch.randn(3 * D, D, generator=g) * D ** -0.5, 0.1 * torch.randn(3 * D, generator=g),
+             torch.randn(D, D, generator=g) * D ** -0.5, 0.1 * torch.randn(D, generator=g),
+             torch.ones(D) + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g),
+             torch.randn(4 * D, D, generator=g) * D ** -0.5, 0.1 * torch.randn(4 * D, generator=g),
+             torch.randn(D, 4 * D, generator=g) * (4 * D) ** -0.5, 0.1 * torch.randn(D, generator=g)]
+        blocks.append([p.to(DEV).requires_grad_() for p in P])
+    x0 = torch.randn(B, T, D, generator=g).to(DEV)
+    gout = torch.randn(B, T, D, generator=g).to(DEV)
+
+    def run(group):
+        for P in blocks:
+            for p in P:
+                p.grad = None
+        x = x0.clone().requires_grad_()
+        with segclip_amd.config.scope(wgrad_group_blocks=group):
+            y = ops.res_stack(x, blocks, H, False, ops.ACT_QUICK_GELU, 1e-5, BF)
+        y.backward(gout)
+        return y.detach(), x.grad.clone(), [[p.grad.clone() for p in P] for P in blocks]
+    assert ops.wgrad_group_plan(nblk, (4 * D * D + 8 * D * D) // 65536, (B * T) // 64, 12) != [1] * nblk
+    y1, dx1, g1 = run(1)
+    y2, dx2, g2 = run(12)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    for a, b in zip(g1, g2):
+        for i, (u, v) in enumerate(zip(a, b)):
+            if i in (2, 4, 8, 10):
+                rel = float((u - v).norm() / u.norm().clamp_min(1e-12))
+                assert rel <= 1e-5, (i, rel)
+            else:
+                assert torch.equal(u, v), i

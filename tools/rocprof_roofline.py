@@ -17,13 +17,13 @@ import tempfile
 
 # kernel class -> substrings of the kernel name
 CLASSES = [
-    ("gemm_bf16", ("gemm_bf16_pq_kernel", "gemm_bf16_p8_kernel", "gemm_bf16_dma_kernel", "gemm_bf16_kernel")),
+    ("gemm_bf16", ("gemm_bf16_pq_kernel", "gemm_bf16_pq_group_kernel", "gemm_bf16_p8_kernel", "gemm_bf16_dma_kernel", "gemm_bf16_kernel")),
     ("splitk_reduce", ("splitk_reduce", "reduce_multi_slabs")),
     ("gemm_f32", ("gemm_f32_kernel",)),
-    ("attn_fwd", ("attn_fwd",)),
-    ("attn_bwd", ("attn_bwd",)),
-    ("ln_fwd", ("ln_fwd_kernel",)),
-    ("ln_bwd", ("ln_bwd_kernel",)),
+    ("attn_fwd", ("attn_fwd", "attn_smallq_fwd")),
+    ("attn_bwd", ("attn_bwd", "attn_smallq_bwd")),
+    ("ln_fwd", ("ln_fwd_kernel", "ln_fwd_multi_kernel")),
+    ("ln_bwd", ("ln_bwd_kernel", "ln_bwd_multi_kernel")),
     ("row_reductions", ("reduce_rows_kernel", "reduce_multi_rows", "colsum_partial_kernel")),
     ("startup_probe", ("spin_kernel",)),   # torch.cuda._sleep of segclip_amd/streams.py: once per process, not per step
 ]

@@ -38,3 +38,19 @@ ks = [k for k in by[key] if k[0] >= w0]
 gl = sorted(((ks[i + 1][0] - ks[i][1], i) for i in range(len(ks) - 1)), reverse=True)[:12]
 for g, i in sorted(gl, key=lambda t: t[1]):
     print(f"gap {g / 1e3:8.1f} us at +{(ks[i][1] - w0) / 1e6:7.2f} ms  after {ks[i][2][:60]}  before {ks[i + 1][2][:60]}")
+# optional 3rd argument N: the launches of ALL streams around the N largest gaps of the busiest stream (who is running
+# while it idles, and what each side was doing just before)
+if len(sys.argv) > 3:
+    allk = sorted((r[2], r[3], r[0], r[4]) for r in rows if r[2] >= w0)
+    for g, i in sorted(gl[:int(sys.argv[3])], key=lambda t: t[1]):
+        gs, ge = ks[i][1], ks[i + 1][0]
+        print(f"--- gap {g / 1e3:.1f} us of stream {key[0]} at +{(gs - w0) / 1e6:.2f} ms")
+        before = [k for k in allk if k[1] <= gs][-10:]
+        during = [k for k in allk if k[0] < ge and k[1] > gs]
+        after = [k for k in allk if k[0] >= ge][:4]
+        for tag, lst in (("before", before), ("during", during[:6] + ([("...",)] if len(during) > 12 else []) + during[-6:] if len(during) > 12 else during), ("after", after)):
+            for k in lst:
+                if len(k) == 1:
+                    print(f"   {tag:7s} ... {len(during) - 12} more")
+                    continue
+                print(f"   {tag:7s} s{k[2]} +{(k[0] - gs) / 1e3:9.1f} us  dur {(k[1] - k[0]) / 1e3:7.1f}  {k[3][:90]}")
