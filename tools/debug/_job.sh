@@ -1,4 +1,8 @@
-mkdir -p gpurun_out/r04w
-timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error|assert|mismatch" | tail -8 | tee gpurun_out/r04w/t_all.txt
-python bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-roofline --force-dist 2>&1 | grep '"metric"' | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/force-dist /" | tee -a gpurun_out/r04w/ab2.txt
-python bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-roofline 2>&1 | grep '"metric"' | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/plain /" | tee -a gpurun_out/r04w/ab2.txt
+OUT=gpurun_out/r04w/step; mkdir -p $OUT
+export TMPDIR=/tmp
+SEGCLIP_BENCH_PROFILE_DIR=$OUT/rl timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic > $OUT/bench_line.json 2> $OUT/bench_line.err
+DB=$(ls $OUT/rl/trace/*.db $OUT/rl/trace/*/*.db 2>/dev/null | head -1)
+python tools/stream_gaps.py $DB 45 > $OUT/stream_gaps.txt 2>&1
+MS=$(grep -o "of [0-9.]* ms" $OUT/stream_gaps.txt | head -1 | grep -o "[0-9.]*")
+python tools/debug/stream_classes.py $DB $MS 30 > $OUT/stream_classes.txt 2>&1
+rm -rf $OUT/rl/trace $OUT/rl/pmc_*

@@ -20,6 +20,12 @@ b dist_bf16wire --no-cpu-baseline --no-roofline --force-dist --wire bf16
 b vitl14 --no-cpu-baseline --no-traffic --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
 b vitl14_fp8 --no-cpu-baseline --no-roofline --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 on
 for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --batch $bsz; done
+# same-box A/B of the grouped weight gradients (config.wgrad_group_blocks): one launch per gradient vs the default, twice
+for rep in a b; do
+  SEGCLIP_WGRAD_GROUP=1 b wgrad_single_$rep --no-cpu-baseline --no-roofline --steps 30 --warmup 8
+  b wgrad_grouped_$rep --no-cpu-baseline --no-roofline --steps 30 --warmup 8
+done
+timeout 300 python tools/debug/center_stage_profile.py 2>&1 | grep -v "$F" | grep -v "Warning\|warn" > $OUT/center_stage.txt
 timeout 300 python tools/bench_hbm.py 2>&1 | grep -v "$F" > $OUT/hbm_kernels.txt
 timeout 300 python tools/bench_gemm.py 2>&1 | grep -v "$F" > $OUT/gemm_shapes.txt
 timeout 300 python tools/bench_gemm.py 19712 text 2>&1 | grep -v "$F" >> $OUT/gemm_shapes.txt

@@ -24,14 +24,18 @@ hdr = ("# Kernel table of the rocprofv3 child that bench.py's roofline block is 
        "# 6 model passes of the child are in the trace; ms/step = total_ms / 6.  at::cuda::spin_kernel = the stream-overlap probe\n"
        "# of segclip_amd/streams.py (once per process, not step work).  Step time of the (unprofiled) parent: %.3f ms.\n"
        "# gemm_bf16_pq_kernel<A_KS,B_KS,MODE>: <0,0,*> forward (0 plain, 2 QuickGELU + one-byte derivative, 5 + fp32 residual),\n"
-       "#   <0,1,*> data gradient (0 plain, 3 x saved derivative), <1,1,4> weight gradient (split-K slabs).\n") % (tag, tag, line["ms_per_step"])
+       "#   <0,1,*> data gradient (0 plain, 3 x saved derivative), <1,1,4> weight gradient (split-K slabs);\n"
+       "# gemm_bf16_pq_group_kernel: the weight gradients of several consecutive blocks as one launch (DESIGN 4.5).\n") % (tag, tag, line["ms_per_step"])
 open(P + "bench_kernel_stats.txt", "w").write(hdr + open(R + "kernel_stats.txt").read())
 cfg = {}
 for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base on one GPU)"), ("full_loss", "--full-loss (BASELINE configs[3])"),
                 ("resid_bf16", "--resid bf16: bf16 residual stream between the blocks of a tower (config.bf16_resid, opt-in)"),
                 ("dist", "--force-dist: N>1 code path (RCCL group, GradSync fp32 wire) on one rank"), ("dist_bf16wire", "--force-dist --wire bf16"),
                 ("vitl14", "--spec vitl14_336 --batch 128 --attn-fp8 off (BASELINE configs[4], bf16 attention)"),
-                ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("b64", "--batch 64"), ("b128", "--batch 128"), ("b512", "--batch 512")):
+                ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("b64", "--batch 64"), ("b128", "--batch 128"), ("b512", "--batch 512"),
+                ("wgrad_single_a", "SEGCLIP_WGRAD_GROUP=1 (one launch per weight gradient), same box, --steps 30"),
+                ("wgrad_grouped_a", "default (grouped weight gradients), same box, --steps 30"),
+                ("wgrad_single_b", "SEGCLIP_WGRAD_GROUP=1, second pass"), ("wgrad_grouped_b", "default, second pass")):
     if not os.path.exists(R + f"bench_{n}.json"):
         continue
     d = last_json(R + f"bench_{n}.json")
@@ -75,6 +79,7 @@ for a, h in (("gemm_shapes.txt", "# GEMM rates per shape (tools/bench_gemm.py, H
              ("gemm_pq.txt", "# gemm_bf16_pq.hip against the 8-phase kernel gemm_bf16_p8.hip per shape and mode, interleaved rounds (tools/bench_pq.py), M = 50176 (vision) and 19712 (text)\n"),
              ("hbm_kernels.txt", "# HBM-bound kernels against 8 TB/s (tools/bench_hbm.py)\n"),
              ("attn.txt", "# attention kernels in isolation (tools/bench_attn.py): T=196 vision (single-pass backward), T=77 causal text\n"),
+             ("center_stage.txt", "# Kernel time of the learnable-center stage alone (SemanticLearnerModule forward + backward, B = 256, bf16, t18 mode;\n# tools/debug/center_stage_profile.py, torch profiler, mean of 3 passes).  Round-3 build: 4.71 ms over 361 launches (DESIGN 4.5)\n"),
              ("stream_gaps.txt", "# tools/stream_gaps.py on the kernel trace of the bench child (profiled run: the host is slower than in the timed run)\n")):
     if os.path.exists(R + a):
         open(P + a, "w").write(h + open(R + a).read())
