@@ -85,6 +85,30 @@ def per_class(table, n_passes):
     return res
 
 
+def class_union_ms(db, n_passes):
+    """{class: ms per step during which AT LEAST ONE kernel of the class is running} - the union of the class's kernel
+    intervals over all streams.  With the two towers on concurrent streams two GEMMs share the chip and each one's duration
+    stretches: the sum of durations double-counts the machine, the union is the time the device spends on the class."""
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select start, end, name from kernels order by start"))
+    c.close()
+    by = {}
+    for s_, e_, name in rows:
+        by.setdefault(classify(name), []).append((s_, e_))
+    out = {}
+    for cls, iv in by.items():
+        cur_s, cur_e, tot = iv[0][0], iv[0][1], 0
+        for s_, e_ in iv[1:]:
+            if s_ > cur_e:
+                tot += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        tot += cur_e - cur_s
+        out[cls] = round(tot / 1e6 / n_passes, 3)
+    return out
+
+
 def format_table(table, n_passes, header="", top=60):
     tot = sum(t for _, _, t, _ in table)
     lines = [header.rstrip()] if header else []
@@ -119,6 +143,12 @@ def measure(child_argv, n_passes, pmc_argv=None, keep_dir=None, timeout=300):
         raise RuntimeError(f"rocprofv3 kernel-trace child failed (rc={rc}): {err[-400:]}")
     table = kernel_table(db)
     res = {"classes": per_class(table, n_passes), "table": table, "child_stdout": out, "traffic": None, "notes": notes}
+    try:
+        for cls, ms in class_union_ms(db, n_passes).items():
+            if cls in res["classes"]:
+                res["classes"][cls]["union_ms_per_step"] = ms
+    except Exception as e:
+        notes.append(f"union busy time not computed: {e}")
     if pmc_argv:
         try:
             pats = dict(CLASSES)["gemm_bf16"]
