@@ -1,39 +1,48 @@
-"""Rewrite the result-table rows of README.md / DESIGN.md from profiles/<tag>_bench_line.json and <tag>_bench_configs.json
-(run after tools/profiles_from_round.py; the prose around the tables is edited by hand)."""
-import json, os, re, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+"""Rewrite the NUMBER cells (pairs/s, ms/step) of the current round's result tables in README.md / DESIGN.md from
+profiles/<tag>_bench_line.json and <tag>_bench_configs.json (run after tools/profiles_from_round.py).  Only the second
+and third cell of a row are touched; the notes column and all prose are edited by hand.  A row is found by its first
+cell (the current round's table comes first in both files, so the first match is the right one)."""
+import json, os, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = json.load(open(f"{ROOT}/profiles/{tag}_bench_line.json")); C = json.load(open(f"{ROOT}/profiles/{tag}_bench_configs.json"))
-r = L["roofline"]; cb = L["cpu_baseline"]
-v = lambda k: round(C[k]["value"]); ms = lambda k, n=1: round(C[k]["ms_per_step"], n)
-rf = lambda k: C[k]["roofline"]
+cb = L["cpu_baseline"]
+v = lambda k: round(C[k]["value"]); ms = lambda k, n=1: f"{C[k]['ms_per_step']:.{n}f}"
 
 
 def sub(path, rows):
     s = open(path).read()
-    for start, new in rows:
-        i = s.index("\n" + start) + 1; j = s.index("\n", i)     # rows are matched at line starts only
-        s = s[:i] + new + s[j:]
+    for first_cell, pairs, msstep in rows:
+        key = "\n| " + first_cell + " |"
+        if key not in s:
+            print(f"{os.path.basename(path)}: row not found: {first_cell[:60]}")
+            continue
+        i = s.index(key) + len(key)
+        j = s.index("|", i)            # end of the pairs/s cell
+        k = s.index("|", j + 1)        # end of the ms/step cell
+        s = s[:i] + f" {pairs} | {msstep} " + s[k:]
     open(path, "w").write(s)
 
 
-frac, tfs, us = r["frac"], r["achieved"], r["avg_launch_us"]
+main = (f"**{round(L['value'])}**", f"{L['ms_per_step']:.2f}")
 sub(f"{ROOT}/README.md", [
-    ("| contrastive only (BASELINE configs[1]) |", f"| contrastive only (BASELINE configs[1]) | **{round(L['value'])}** | {L['ms_per_step']:.2f} | round 2: 5248 / 48.78, round 1: 4492 / 57.0.  {100 * r['step_frac']:.1f} % of the 2.5 PF bf16 roofline on 109.675 GF/pair; bf16 GEMM kernels, all 340 launches of a step, KERNEL time from rocprofv3 with both streams active: {us:.1f} us per launch = {tfs:.0f} TF/s (`roofline.frac` {frac:.3f}, reproducible from `profiles/{tag}_bench_kernel_stats.txt`); HBM traffic per GEMM launch measured in the same run: {r['traffic'] / 1e6:.0f} MB against 200 MB algorithmic (round 2: 300) |"),
-    ("| same, global batch 2048 on one GPU (`--global-batch 2048`) |", f"| same, global batch 2048 on one GPU (`--global-batch 2048`) | {v('gb2048')} | {ms('gb2048')} | round 2: 5902 / 347.0; GEMM {rf('gb2048')['achieved']:.0f} TF/s over all launches ({rf('gb2048')['frac']:.3f}) |"),
-    ("| full SegCLIP loss (configs[3]) |", f"| full SegCLIP loss (configs[3]) | {v('full_loss')} | {ms('full_loss', 2)} | round 2: 3349 / 76.4; `step_frac` {rf('full_loss')['step_frac']:.3f} |"),
-    ("| through the N>1 code path on one rank", f"| through the N>1 code path on one rank (RCCL group + GradSync, fp32 wire; `--force-dist`) | {v('dist')} | {ms('dist', 2)} | {ms('dist', 2) - L['ms_per_step']:+.1f} ms (round 2: +1.7); bf16 wire: {ms('dist_bf16wire', 2)} |"),
-    ("| ViT-L/14 336^2, B=128 (configs[4], `--spec vitl14_336`) |", f"| ViT-L/14 336^2, B=128 (configs[4], `--spec vitl14_336`) | {v('vitl14')} bf16 / {v('vitl14_fp8')} fp8 attention | {ms('vitl14')} / {ms('vitl14_fp8')} | round 2: 1202 / 1178; `step_frac` {rf('vitl14')['step_frac']:.3f} |"),
-    ("| per-GPU batch 64 / 128 / 512 |", f"| per-GPU batch 64 / 128 / 512 | {v('b64')} / {v('b128')} / {v('b512')} | {ms('b64')} / {ms('b128')} / {ms('b512')} | B=64 is host-bound (16-18 ms of Python + launches per step, un-profiled) |"),
-    ("| reference CPU path (oracle, B=4, the box's 16 usable cores) |", f"| reference CPU path (oracle, B=4, the box's {cb['cores']} usable cores) | {cb['value']:.1f} | {4000 / cb['value']:.0f} | `cpu_baseline` of the same run (full loss {cb.get('full_loss_value', 0):.1f}) |"),
+    ("contrastive only (BASELINE configs[1])", *main),
+    ("same, global batch 2048 on one GPU (`--global-batch 2048`)", v("gb2048"), ms("gb2048")),
+    ("full SegCLIP loss (configs[3])", v("full_loss"), ms("full_loss", 2)),
+    ("bf16 residual stream (`--resid bf16`, opt-in)", v("resid_bf16"), ms("resid_bf16", 2)),
+    ("through the N>1 code path on one rank (RCCL group + GradSync, fp32 wire; `--force-dist`)", v("dist"), ms("dist", 2)),
+    ("ViT-L/14 336^2, B=128 (configs[4], `--spec vitl14_336`; `--attn-fp8 auto` = off)", f"{v('vitl14')} bf16 / {v('vitl14_fp8')} fp8 attention", f"{ms('vitl14')} / {ms('vitl14_fp8')}"),
+    ("per-GPU batch 64 / 128 / 512", f"{v('b64')} / {v('b128')} / {v('b512')}", f"{ms('b64')} / {ms('b128')} / {ms('b512')}"),
+    ("reference CPU path (oracle, B=4, the box's 16 usable cores)", f"{cb['value']:.1f}", f"{4000 / cb['value']:.0f}"),
 ])
 sub(f"{ROOT}/DESIGN.md", [
-    ("| contrastive only, B=256 (BASELINE configs[1]) |", f"| contrastive only, B=256 (BASELINE configs[1]) | **{round(L['value'])}** | {L['ms_per_step']:.2f} | round 2: 5248 / 48.78, round 1: 4492 / 57.0.  `step_frac` {r['step_frac']:.3f}; bf16 GEMM class {r['time_per_step_ms']:.1f} ms of kernel time per step on two streams = {us:.1f} µs per launch = {tfs:.0f} TF/s (`frac` {frac:.3f}); HBM traffic per GEMM launch {r['traffic'] / 1e6:.0f} MB vs 200 MB algorithmic |"),
-    ("| same through the N>1 path, 1-rank RCCL group,", f"| same through the N>1 path, 1-rank RCCL group, GradSync fp32 wire (`--force-dist`) | {v('dist')} | {ms('dist', 2)} | {ms('dist', 2) - L['ms_per_step']:+.1f} ms (round 2: +1.7); bf16 wire {ms('dist_bf16wire', 2)} |"),
-    ("| contrastive only, global batch 2048 on one GPU", f"| contrastive only, global batch 2048 on one GPU (`--global-batch 2048`, SURVEY §8d strong-scaling base) | {v('gb2048')} | {ms('gb2048')} | `step_frac` {rf('gb2048')['step_frac']:.3f}; GEMM {rf('gb2048')['achieved']:.0f} TF/s over all launches (`frac` {rf('gb2048')['frac']:.3f}) |"),
-    ("| full SegCLIP loss (configs[3], `--full-loss`) |", f"| full SegCLIP loss (configs[3], `--full-loss`) | {v('full_loss')} | {ms('full_loss', 2)} | 144.07 GF per pair: `step_frac` {rf('full_loss')['step_frac']:.3f}; round 2: 3349 / 76.4 |"),
-    ("| ViT-L/14 336², B=128 (configs[4], `--spec vitl14_336`) |", f"| ViT-L/14 336², B=128 (configs[4], `--spec vitl14_336`) | {v('vitl14')} (bf16 attention) / {v('vitl14_fp8')} (fp8 forward) | {ms('vitl14')} / {ms('vitl14_fp8')} | 535.3 GF per pair: `step_frac` {rf('vitl14')['step_frac']:.3f}; GEMM {rf('vitl14')['achieved']:.0f} TF/s over all launches ({rf('vitl14')['frac']:.3f}); round 2: 1202 / 1178; §8.4 |"),
-    ("| pairs/s | ", f"| pairs/s | {v('b64')} | {v('b128')} | {round(L['value'])} | {v('b512')} | {v('gb2048')} |"),
-    ("| ms/step | ", f"| ms/step | {ms('b64')} | {ms('b128')} | {L['ms_per_step']:.1f} | {ms('b512')} | {ms('gb2048')} |"),
+    ("contrastive only, B=256 (BASELINE configs[1])", *main),
+    ("bf16 residual stream (`--resid bf16`, opt-in, §2)", v("resid_bf16"), ms("resid_bf16", 2)),
+    ("same through the N>1 path, 1-rank RCCL group, GradSync fp32 wire (`--force-dist`)", v("dist"), ms("dist", 2)),
+    ("contrastive only, global batch 2048 on one GPU (`--global-batch 2048`, SURVEY §8d strong-scaling base)", v("gb2048"), ms("gb2048")),
+    ("full SegCLIP loss (configs[3], `--full-loss`)", v("full_loss"), ms("full_loss", 2)),
+    ("ViT-L/14 336², B=128 (configs[4], `--spec vitl14_336`; `--attn-fp8 auto` = off)",
+     f"{v('vitl14')} (bf16 attention) / {v('vitl14_fp8')} (fp8 forward, `--attn-fp8 on`)", f"{ms('vitl14')} / {ms('vitl14_fp8')}"),
+    ("per-GPU batch 64 / 128 / 512", f"{v('b64')} / {v('b128')} / {v('b512')}", f"{ms('b64')} / {ms('b128')} / {ms('b512')}"),
 ])
-print("tables rewritten from profiles/%s_*" % tag)
+print("number cells rewritten from profiles/%s_*; notes and prose are hand-edited" % tag)
