@@ -186,6 +186,7 @@ def wgrad_group_plan(nblk, tiles_blk, ksteps, gmax):
 
 
 _PQ_TAIL_ENV = os.environ.get("SEGCLIP_PQ_TAIL", "0") not in ("", "0")
+_SHARED_RQ = os.environ.get("SEGCLIP_SHARED_RQ", "1") != "0"   # A/B: one reduce queue per weight-gradient group (1) or per block (0)
 
 
 def _empty(shape, dtype, like):
@@ -921,7 +922,7 @@ def _aux_kind(act_dtype, act, M=0, N=0):
 
 
 def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap_wgrad=False, keep=None, reduce_side=None,
-                  wgroup=None):
+                  wgroup=None, rqueue=None):
     """Hand-scheduled backward of one block.  g: fp32 (M, D) gradient of the block output or None; g16: its bf16 copy or
     None.  need[i]: gradient wanted for forward input i (0 = x, 1..12 = the parameters in forward order).
     chain=False: fp32 residual gradient in and out (plus the bf16 copy the LayerNorm backward emits for free).
@@ -962,7 +963,10 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
 
     # the block's trailing reductions (split-K combines, LayerNorm / bias column sums) are queued and flushed as two
     # launches at the end of the block (not when the weight gradients run on the side stream)
-    rq = ReduceQueue() if side is None else None
+    # rqueue (ResStackFn with grouped weight gradients): the caller's queue - the trailing reductions of all blocks of a group
+    # are flushed together (2 launches per 16 entries instead of 2 per block)
+    own_rq = rqueue is None or side is not None
+    rq = (ReduceQueue() if side is None else None) if own_rq else rqueue
     if side is not None:
         wgroup = None
 
@@ -1010,7 +1014,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     r = p_ln_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dx1, dx_dtype=rdt, want_bf16=two, want_dres_colsum=True,
                  outs=(_slot_out(s_ln1w, (D,)) if need[1] else None, _slot_out(s_ln1b, (D,)) if need[2] else None,
                        _slot_out(s_bo, (D,)) if need[6] else None), defer=rq)
-    if rq is not None:
+    if rq is not None and own_rq:
         rq.flush(reduce_side)
     dln1w, dln1b = r[1], r[2]
     dbo = r[-1] if need[6] else None                             # colsum(dx1), fused into the LN1 backward
@@ -1142,6 +1146,7 @@ class ResStackFn(Function):
                 sizes = wgrad_group_plan(nblk, tiles_blk, (B * T) // 64, gmax)
                 wg = WgradGroup() if max(sizes) > 1 else None
         left = sizes.pop(0) if wg is not None else 0
+        grq = ReduceQueue() if (wg is not None and rside is None and _SHARED_RQ) else None
         pending = []
         for b in reversed(range(nblk)):
             P = ctx.params[b * 12:(b + 1) * 12]
@@ -1150,13 +1155,15 @@ class ResStackFn(Function):
             gslots = (sl[2], sl[4], sl[8], sl[10])
             vslots = (sl[0], sl[1], sl[3], sl[5], sl[6], sl[7], sl[9], sl[11])
             cur32, cur16, grads = _resblock_bwd(saved[b * N_SAVED:(b + 1) * N_SAVED], ctx.cfg, ctx.klen, gslots, vslots,
-                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep, rside, wg)
+                                                need, cur32, cur16, ctx.chain, ctx.overlap_wgrad, keep, rside, wg, grq)
             pending.append((b, P, sl, grads))
             if wg is not None:
                 left -= 1
                 if left > 0 and b > 0:
                     continue
                 wg.flush()
+                if grq is not None:
+                    grq.flush()
                 left = sizes.pop(0) if sizes else nblk
             for b_, P_, sl_, grads_ in pending:
                 for i, (p, gr, slot) in enumerate(zip(P_, grads_, sl_)):

@@ -1,10 +1,2 @@
-mkdir -p gpurun_out/r04w
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic 2>&1 | grep '"metric"' > gpurun_out/r04w/bench_union.json
-python - <<'PY'
-import json
-d = json.load(open("gpurun_out/r04w/bench_union.json"))
-r = d["roofline"]
-print(d["value"], d["ms_per_step"], "frac", r["frac"], "achieved", r["achieved"], "time", r["time_per_step_ms"], "union", r["union_ms_per_step"], r["achieved_union"], r["frac_union"], "step_frac", r["step_frac"])
-for k, v in r["classes"].items():
-    print(k, v)
-PY
+mkdir -p gpurun_out/r04v
+for i in 1 2 3; do for v in 0 1; do SEGCLIP_SHARED_RQ=$v python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline 2>&1 | grep '"metric"' | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/shared_rq=$v /" | tee -a gpurun_out/r04v/ab2.txt; done; done
