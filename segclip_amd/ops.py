@@ -152,9 +152,9 @@ class WgradGroup:
         splits = lib.segclip_wgrad_group_splits(tiles, R // 64)
         nbytes = lib.segclip_wgrad_group_ws_bytes(arr, len(items), splits)
         ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=items[0][0].device)
-        if _OpCount.enabled:
-            for dy, x, dw in items:
-                _OpCount.add("gemm_bf16", 2.0 * R * dy.shape[1] * x.shape[1], 2 * R * (dy.shape[1] + x.shape[1]) + 4 * dw.numel())
+        if _OpCount.enabled:   # ONE launch: its flops / algorithmic bytes are the sums over the problems
+            _OpCount.add("gemm_bf16", sum(2.0 * R * dy.shape[1] * x.shape[1] for dy, x, dw in items),
+                         sum(2 * R * (dy.shape[1] + x.shape[1]) + 4 * dw.numel() for dy, x, dw in items))
         try:
             L.check(lib.segclip_wgrad_group(arr, len(items), R, splits, L.ptr(ws), nbytes, L.stream()), "wgrad_group")
         except L.Unsupported:
