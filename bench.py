@@ -364,6 +364,8 @@ def main():
         segclip_amd.config.reduce_side = True
     if a.text_after_blocks >= 0:
         segclip_amd.config.text_after_blocks = a.text_after_blocks
+    if os.environ.get("SEGCLIP_OVERLAP_TOWERS", "1") == "0":   # experiment: both towers on one stream
+        segclip_amd.config.overlap_towers = False
     if os.environ.get("SEGCLIP_OVERLAP_WGRAD", "0") == "1":   # experiment switch: weight gradients on a second stream
         segclip_amd.config.overlap_wgrad = True
     torch.manual_seed(1234 + rank)
