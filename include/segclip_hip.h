@@ -87,7 +87,10 @@ typedef struct segclip_gemm_desc {
   float* colsum_ws;
   int32_t flags;    /* SEGCLIP_GEMM_DEFER_*: leave the trailing reduction launches to the caller (segclip_reduce_multi):
                        the split-K slabs stay in ws, the column-sum partials in colsum_ws */
-  int32_t reserved2;
+  int32_t res_row_mod; /* > 0: the residual of output row m is residual row (m % res_row_mod) - a (T, N) table broadcast over
+                          the B samples of an (B*T, N) output (the positional table added to the patch embedding,
+                          modules/module_clip_vtransformer.py:56-64) without a batched launch.  Honoured for fp32 outputs
+                          with an fp32 residual on full 256 x 256 bf16 tiles; otherwise SEGCLIP_ERR_UNSUPPORTED. */
 } segclip_gemm_desc;
 
 #define SEGCLIP_GEMM_DEFER_SPLITK 1 /* do not launch the split-K combine: C is NOT written; combine ws later */

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("bsR1", i64), ("bsR2", i64),
                 ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("r_dtype", i32),
                 ("act", i32), ("mul_dact", i32), ("alpha", f32), ("aux_kind", i32),
-                ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp), ("flags", i32), ("reserved2", i32)]
+                ("ws", vp), ("ws_bytes", i64), ("colsum", vp), ("colsum_ws", vp), ("flags", i32), ("res_row_mod", i32)]
 
 
 class ReduceEntry(C.Structure):

@@ -41,6 +41,10 @@ extern "C" int segclip_gemm(const segclip_gemm_desc* d, void* stream) {
                   "gemm: aux_kind 1 / 2 (aux = act'(pre-activation)) is implemented for QuickGELU only");
   SEGCLIP_REQUIRE(d->aux_kind != 2 || (d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16 && d->c_dtype == SEGCLIP_BF16),
                   "gemm: aux_kind 2 (one byte per element) needs bf16 operands and output");
+  if (d->res_row_mod > 0 && !(d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16)) {
+    segclip_set_error("gemm: res_row_mod is a bf16-operand feature");
+    return SEGCLIP_ERR_UNSUPPORTED;
+  }
   if (d->a_dtype == SEGCLIP_F32 && d->b_dtype == SEGCLIP_F32) {
     SEGCLIP_REQUIRE(d->c_dtype == SEGCLIP_F32 && (!d->residual || d->r_dtype == SEGCLIP_F32),
                     "gemm f32: output / residual must be f32");

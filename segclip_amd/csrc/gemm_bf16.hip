@@ -484,7 +484,13 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
     }
     g.colsum_part = d->colsum_ws;
   }
-  if (want_dma(d)) {
+  if (d->res_row_mod > 0) {   // only gemm_bf16_pq.hip's fp32-residual epilogue addresses the residual modulo a row count
+    launched = want_dma(d) && nb == 1 && g.splits == 1 && segclip_gemm_bf16_pq_try(d, &g, 1, nb, stream);
+    if (!launched) {
+      segclip_set_error("gemm: res_row_mod needs the fp32-residual epilogue on full 256 x 256 bf16 tiles");
+      return SEGCLIP_ERR_UNSUPPORTED;
+    }
+  } else if (want_dma(d)) {
     static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
     // 256x256 tiles: the phase-pipelined kernel (gemm_bf16_p8.hip); 256x128 / 128x128 tiles: the one-barrier-per-K-tile
     // kernel (gemm_bf16_dma.hip)

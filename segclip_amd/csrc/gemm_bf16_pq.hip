@@ -65,6 +65,7 @@ struct PQArgs {
   // tile to arrive (tail_cnt[tile], zeroed by the host) sums them in K-range order and runs the epilogue
   int tail_S, tail_r, nfull;
   float* tail_ws; int* tail_cnt;
+  int rmod;              // PQ_RES32: > 0 -> residual row = output row % rmod (a table broadcast over the samples)
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
@@ -476,6 +477,14 @@ template <int I, int Q>
 __device__ __forceinline__ void pq_res32_issue(const PQArgs& g, int lane, int wave, int64_t m0, int64_t n0, f32x4 (&res)[8]) {
   const int J = wave >> 2, rb = (wave & 3) * 32;
   const int r2 = lane >> 5, c = lane & 31;
+  if (g.rmod > 0) {   // broadcast table: its rows are re-read by every sample - ordinary (cached) loads
+    const float* rt = reinterpret_cast<const float*>(g.side) + n0 + J * 128 + c * 4;
+    const int64_t row0 = m0 + I * 128 + rb + r2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      res[k] = *reinterpret_cast<const f32x4*>(rt + ((row0 + (Q * 8 + k) * 2) % g.rmod) * g.lds);
+    return;
+  }
   const float* rq = reinterpret_cast<const float*>(g.side) + (m0 + I * 128 + rb + r2) * g.lds + n0 + J * 128 + c * 4;
 #pragma unroll
   for (int k = 0; k < 8; ++k) res[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rq + (int64_t)(Q * 8 + k) * 2 * g.lds));
@@ -913,6 +922,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     return true;
   }
   if (splits != 1) return false;
+  if (d->res_row_mod > 0 && !(d->c_dtype == SEGCLIP_F32 && d->residual != nullptr && d->r_dtype == SEGCLIP_F32)) return false;
   if (d->c_dtype == SEGCLIP_F32) {   // forward + fp32 residual -> fp32 (the fp32 residual stream): fp32 patches, fp32 row pass
     static const int r32_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ_RES32"); return e ? atoi(e) : 1; }();
     if (!r32_env || b_ks || d->residual == nullptr || d->r_dtype != SEGCLIP_F32 || d->alpha != 1.0f) return false;
@@ -923,7 +933,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     if (256 * d->sam * 2 >= (int64_t)1 << 31 || 256 * d->sbn * 2 >= (int64_t)1 << 31 || 256 * d->ldc * 4 >= (int64_t)1 << 31) return false;
     PQArgs g = {};
     g.A = reinterpret_cast<const bf16_t*>(d->A); g.B = reinterpret_cast<const bf16_t*>(d->B);
-    g.bias = d->bias; g.side = d->residual; g.lds = d->ldr;
+    g.bias = d->bias; g.side = d->residual; g.lds = d->ldr; g.rmod = d->res_row_mod > 0 ? d->res_row_mod : 0;
     g.lda = d->sam; g.ldb = d->sbn; g.Cf = reinterpret_cast<float*>(d->C); g.ldc = d->ldc;
     g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
     g.abl = mode_env == 2 ? segclip_ablation_env("SEGCLIP_PQ_ABL") : 0;

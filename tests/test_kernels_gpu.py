@@ -1083,3 +1083,36 @@ def test_res_stack_grouped_weight_gradients_match_per_block():
                 assert rel <= 1e-5, (i, rel)
             else:
                 assert torch.equal(u, v), i
+
+
+@pytest.mark.parametrize("M,N,K,T", [(1024, 256, 256, 196), (12544, 768, 768, 196), (512, 512, 128, 49)])
+def test_gemm_residual_table_broadcast_over_samples(M, N, K, T):
+    """segclip_gemm with res_row_mod: C[m] = A[m] W^T + table[m % T] in fp32 - the positional table added to the patch
+    embedding (modules/module_clip_vtransformer.py:56-64) as ONE (B*T, D) GEMM instead of B problems of T rows."""
+    a, w = rnd(M, K, dtype=BF, seed=301), rnd(N, K, dtype=BF, seed=302, scale=K ** -0.5)
+    table = rnd(T + 1, N, seed=303)                       # row 0 = the class-token row the caller skips (r_off)
+    out = torch.empty(M, N, device=DEV)
+    ops.p_gemm(a, w, out, M, N, K, (K, 1), (K, 1), N, residual=table, ldr=N, r_off=N, r_mod=T)
+    ref = a.float() @ w.float().t() + table[1:][torch.arange(M, device=DEV) % T]
+    close(out, ref, 1e-5, 1e-4, "gemm + table[m % T]")
+    # not covered (an f32 problem, or a bf16 output): nothing is launched and the caller is told
+    with pytest.raises(ops.L.Unsupported):
+        ops.p_gemm(a.float(), w.float(), out, M, N, K, (K, 1), (K, 1), N, residual=table, ldr=N, r_off=N, r_mod=T)
+
+
+def test_patch_embedding_one_gemm_matches_batched_form():
+    """PatchEmbedFn at a batch whose token count is a multiple of 256 (one GEMM with the row-modulo residual) against the
+    same Function in fp32 mode (batched form, exact-f32 GEMM): bf16-operand tolerance, and gradients flow to conv1 / pos."""
+    B, p, D = 64, 16, 768
+    img = rnd(B, 3, 224, 224, seed=311)
+    conv_w = rnd(D, 3, p, p, seed=312, scale=(3 * p * p) ** -0.5)
+    cls, pos = rnd(D, seed=313), rnd(197, D, seed=314, scale=0.1)
+    outs = {}
+    for dt in (F32, BF):
+        t = [v.detach().clone().requires_grad_() for v in (conv_w, cls, pos)]
+        x = ops.PatchEmbedFn.apply(img, t[0], t[1], t[2], p, dt)
+        x.backward(torch.ones_like(x) * 1e-3)
+        outs[dt] = (x.detach(), t[0].grad, t[2].grad)
+    close(outs[BF][0], outs[F32][0], 2e-2, 2e-2, "patch embedding")
+    close(outs[BF][1], outs[F32][1], 3e-2, 3e-2 * float(outs[F32][1].abs().max()), "d conv1")
+    close(outs[BF][2], outs[F32][2], 1e-5, 1e-5, "d pos")
