@@ -1,0 +1,93 @@
+"""Rewrite the figures that the round-4 NOTES of README.md / DESIGN.md quote from profiles/r04_bench_line.json,
+r04_bench_configs.json and r04_eager_ab.json (run after tools/profiles_from_round.py r04 and tools/doc_numbers.py r04).
+Each note is regenerated as a whole from a template here, so the docs and the committed profile cannot drift apart."""
+import json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = json.load(open(f"{ROOT}/profiles/r04_bench_line.json")); C = json.load(open(f"{ROOT}/profiles/r04_bench_configs.json"))
+E = json.load(open(f"{ROOT}/profiles/r04_eager_ab.json"))
+r = L["roofline"]; cl = r["classes"]; cb = L["cpu_baseline"]
+rf = lambda k: C[k]["roofline"]
+ms = lambda k, n=2: f"{C[k]['ms_per_step']:.{n}f}"
+single = (C["wgrad_single_a"]["ms_per_step"] + C["wgrad_single_b"]["ms_per_step"]) / 2
+grouped = (C["wgrad_grouped_a"]["ms_per_step"] + C["wgrad_grouped_b"]["ms_per_step"]) / 2
+
+
+def setnote(s, first, note, cells=None):
+    key = "\n| " + first + " |"
+    i = s.index(key) + len(key)
+    j = s.index("|", i); k = s.index("|", j + 1)
+    if cells:
+        s = s[:i] + f" {cells[0]} | {cells[1]} " + s[k:]
+        j = s.index("|", i); k = s.index("|", j + 1)
+    e = s.index("\n", k)
+    return s[:k + 1] + " " + note + " |" + s[e:]
+
+
+ratio = r["traffic"] / r["algorithmic_bytes_per_launch"]
+dist_delta = C["dist"]["ms_per_step"] - L["ms_per_step"]
+s = open(f"{ROOT}/README.md").read()
+s = setnote(s, "contrastive only (BASELINE configs[1])",
+            "other boxes of the round gave 36.9-39.3 ms for the same build (boxes differ by up to 6 %; every line of a table comes from ONE box; same-box A/Bs are "
+            "quoted where a change is claimed).  Round 3: 5869 / 43.62 (its driver box: 5797 / 44.16), round 2: 5248 / 48.78, round 1: 4492 / 57.0.  "
+            f"{100 * r['step_frac']:.1f} % of the 2.5 PF bf16 roofline on 109.675 GF/pair (`step_frac`); bf16 GEMM kernels, all {r['launches_per_step']:.0f} launches of a step (the weight "
+            f"gradients of several blocks are one launch now), KERNEL time from rocprofv3 with both streams active: {r['avg_launch_us']:.1f} us per launch = {r['achieved']:.0f} TF/s "
+            f"(`roofline.frac` {r['frac']:.3f}, reproducible from `profiles/r04_bench_kernel_stats.txt`); time during which at least one GEMM runs: {r['union_ms_per_step']:.1f} ms per step = "
+            f"{r['achieved_union']:.0f} TF/s (`frac_union` {r['frac_union']:.3f} - two towers' GEMMs sharing the chip each take longer, the sum of durations counts the machine twice); HBM traffic "
+            f"per GEMM launch measured in the same run: {r['traffic'] / 1e6:.0f} MB against {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic ({ratio:.2f}x; round 3: 1.46x)")
+s = setnote(s, "same-node yardstick: PyTorch-ROCm eager (bf16 autocast + SDPA) on the same model math (`tools/bench_eager.py`)",
+            f"this build: {E['speedup_vs_eager']}x (`profiles/r04_eager_ab.json`)", (round(E["pairs_per_s"]), f"{E['ms_per_step']:.1f}"))
+s = setnote(s, "same, global batch 2048 on one GPU (`--global-batch 2048`)",
+            f"round 3: 6622 / 309.3; GEMM {rf('gb2048')['achieved']:.0f} TF/s over all launches ({rf('gb2048')['frac']:.3f}); `step_frac` {rf('gb2048')['step_frac']:.3f}")
+s = setnote(s, "full SegCLIP loss (configs[3])", f"round 3: 3798 / 67.4; `step_frac` {rf('full_loss')['step_frac']:.3f}")
+s = setnote(s, "through the N>1 code path on one rank (RCCL group + GradSync, fp32 wire; `--force-dist`)",
+            f"{dist_delta:+.1f} ms (weight-gradient groups capped at 3 blocks while bucket slots are active); bf16 wire: {ms('dist_bf16wire')}")
+s = setnote(s, "ViT-L/14 336^2, B=128 (configs[4], `--spec vitl14_336`; `--attn-fp8 auto` = off)",
+            f"round 3 (another box): 1308 / 1281; `step_frac` {rf('vitl14')['step_frac']:.3f}; GEMM {rf('vitl14')['achieved']:.0f} TF/s over all launches ({rf('vitl14')['frac']:.3f})")
+s = setnote(s, "per-GPU batch 64 / 128 / 512", "B=64 is host-bound (launch enqueue, un-profiled)")
+s = setnote(s, "reference CPU path (oracle, B=4, the box's 16 usable cores)", f"`cpu_baseline` of the same run (full loss {cb.get('full_loss_value', 0):.1f})")
+import re
+s = re.sub(r"same-box A/B [0-9.]+ -> [0-9.]+ ms per step \(`profiles/r04_bench_configs.json`", f"same-box A/B {single:.2f} -> {grouped:.2f} ms per step (`profiles/r04_bench_configs.json`", s)
+open(f"{ROOT}/README.md", "w").write(s)
+
+s = open(f"{ROOT}/DESIGN.md").read()
+s = setnote(s, "contrastive only, B=256 (BASELINE configs[1])",
+            f"round 3: 5869 / 43.62 (driver box 5797 / 44.16), round 2: 5248 / 48.78, round 1: 4492 / 57.0.  `step_frac` {r['step_frac']:.3f}; bf16 GEMM class {r['time_per_step_ms']:.1f} ms of kernel "
+            f"time per step on two streams over {r['launches_per_step']:.0f} launches = {r['avg_launch_us']:.1f} µs per launch = {r['achieved']:.0f} TF/s (`frac` {r['frac']:.3f}); at least one GEMM running during "
+            f"{r['union_ms_per_step']:.1f} ms per step = {r['achieved_union']:.0f} TF/s (`frac_union` {r['frac_union']:.3f}); HBM traffic per GEMM launch {r['traffic'] / 1e6:.0f} MB vs "
+            f"{r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic ({ratio:.2f}×)")
+s = setnote(s, "same-node yardstick: PyTorch-ROCm eager, bf16 autocast + SDPA, same model math (`tools/bench_eager.py`)",
+            f"`profiles/r04_eager_ab.json`: this build is {E['speedup_vs_eager']}× eager on the same box; per-class rows: torch layer_norm fwd / bwd 85 / 223 µs at 50176×768 (here 44 / 131), SDPA fwd / bwd "
+            "177 / 832 µs at T = 196 (here 113 / 312)", (round(E["pairs_per_s"]), f"{E['ms_per_step']:.1f}"))
+s = setnote(s, "same through the N>1 path, 1-rank RCCL group, GradSync fp32 wire (`--force-dist`)",
+            f"{dist_delta:+.1f} ms (round 3: +1.0; weight-gradient groups capped at 3 blocks); bf16 wire {ms('dist_bf16wire')}")
+s = setnote(s, "contrastive only, global batch 2048 on one GPU (`--global-batch 2048`, SURVEY §8d strong-scaling base)",
+            f"`step_frac` {rf('gb2048')['step_frac']:.3f}; GEMM {rf('gb2048')['achieved']:.0f} TF/s over all launches (`frac` {rf('gb2048')['frac']:.3f}); round 3: 6622 / 309.3")
+s = setnote(s, "full SegCLIP loss (configs[3], `--full-loss`)", f"144.07 GF per pair: `step_frac` {rf('full_loss')['step_frac']:.3f}; round 3: 3798 / 67.4")
+s = setnote(s, "ViT-L/14 336², B=128 (configs[4], `--spec vitl14_336`; `--attn-fp8 auto` = off)",
+            f"`step_frac` {rf('vitl14')['step_frac']:.3f}; GEMM {rf('vitl14')['achieved']:.0f} TF/s ({rf('vitl14')['frac']:.3f}); round 3 (another box): 1308 / 1281")
+a = s.index("Per step, kernel time by class (`profiles/r04_bench_line.json`")
+b = s.index("; 644 dispatches per step", a)
+tab = {}
+for l in open(f"{ROOT}/profiles/r04_bench_kernel_stats.txt"):
+    m = re.match(r"(.*?)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", l)
+    if m and "gemm_bf16" in m.group(1):
+        tab[m.group(1).strip()] = float(m.group(6))
+def g(*pats):
+    return sum(v for k, v in tab.items() if all(p in k for p in pats))
+small = sum(v for k, v in tab.items() if "dma_kernel" in k or "p8_kernel" in k or "gemm_bf16_kernel" in k or "<true, true, 4>" in k)
+para = (f"Per step, kernel time by class (`profiles/r04_bench_line.json`, both streams; round 3 in brackets): bf16 GEMM {cl['gemm_bf16']['time_per_step_ms']:.1f} ms [40.4]\n"
+        f"(plain data gradients {g('pq_kernel<false, true, 0>'):.1f}, grouped weight gradients {g('pq_group_kernel'):.1f}, × derivative {g('pq_kernel<false, true, 3>'):.1f}, + fp32 residual {g('pq_kernel<false, false, 5>'):.1f}, "
+        f"QuickGELU + derivative {g('pq_kernel<false, false, 2>'):.1f}, plain forward\n{g('pq_kernel<false, false, 0>'):.1f}, 128-wide-tile and fallback kernels {small:.1f} - the non-weight-gradient kernels each take "
+        "longer than in the first half of the round because they now\noverlap more with the other tower's; the union figure above is the device's view), "
+        f"attention backward {cl['attention_bwd']['time_per_step_ms']:.2f} [5.1] / forward {cl['attention_fwd']['time_per_step_ms']:.2f} [2.3],\n"
+        f"LayerNorm backward {cl['layernorm_bwd']['time_per_step_ms']:.2f} [3.0] / forward {cl['layernorm_fwd']['time_per_step_ms']:.2f} [2.0], split-K combines {cl['splitk_reduce']['time_per_step_ms']:.2f} [1.8], "
+        f"row reductions {cl['row_reductions']['time_per_step_ms']:.2f} over {cl['row_reductions']['launches_per_step']:.0f}\nlaunches [1.1 over 80], f32 GEMM {cl['gemm_f32']['time_per_step_ms']:.2f} [0.6], "
+        f"other {cl['other']['time_per_step_ms']:.2f} over {cl['other']['launches_per_step']:.0f} launches [2.5 over 205]")
+s = s[:a] + para + s[b:]
+s = re.sub(r"per step on one box, [0-9.]+ → [0-9.]+ on the profile box", f"per step on one box, {single:.2f} → {grouped:.2f} on the profile box", s)
+s = re.sub(r"same-box step [0-9.]+ → [0-9.]+ ms; §4.5 \|", f"same-box step {single:.2f} → {grouped:.2f} ms; §4.5 |", s)
+s = re.sub(r"`frac` 0\.\d+ in `profiles/r04_bench_line.json`\), while the union", f"`frac` {r['frac']:.3f} in `profiles/r04_bench_line.json`), while the union", s)
+s = re.sub(r"at the same time \(`frac_union` 0\.\d+\)", f"at the same time (`frac_union` {r['frac_union']:.3f})", s)
+s = re.sub(r"\d+ pairs/s eager vs \d+ \([0-9.]+×\); per-class rows", f"{round(E['pairs_per_s'])} pairs/s eager vs {round(L['value'])} ({E['speedup_vs_eager']}×); per-class rows", s)
+open(f"{ROOT}/DESIGN.md", "w").write(s)
+print("notes rewritten")
