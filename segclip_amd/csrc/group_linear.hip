@@ -13,6 +13,8 @@
 // per (input, output) pair with SWAPPED operands (result block transposed: lane = row, registers = 4 consecutive columns),
 // bf16 packing in-lane, and the 32 x 64 output block through a wave-private 4-KiB LDS patch so that it leaves as whole
 // 128-byte lines.  The next group's row fragments are in flight while the current group is multiplied.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -36,6 +38,11 @@ __global__ __launch_bounds__(GL_WAVES * 64) void group_linear_kernel(GLArgs a) {
   const int64_t row0 = ((int64_t)blockIdx.x * GL_WAVES + wave) * GL_ROWS;
   if (row0 >= a.M) return;
   const int64_t row = row0 + li < a.M ? row0 + li : a.M - 1;      // clamped: rows beyond M are computed and not stored
+  // blockIdx.y: a contiguous share of the groups (more waves in flight: a wave's walk is a chain of load -> MFMA -> LDS -> store;
+  // 6 shares: 101 + 89 -> 81 + 77 us for the two launches of a step, SEGCLIP_GL64_GSPLIT)
+  const int gper = (a.groups + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int gbeg = (int)blockIdx.y * gper, gend = gbeg + gper < a.groups ? gbeg + gper : a.groups;
+  if (gbeg >= gend) return;
   const bf16_t* xin[NIN];
 #pragma unroll
   for (int i = 0; i < NIN; ++i) xin[i] = a.in[i] + row * a.ld_in[i] + 8 * lk;
@@ -43,13 +50,13 @@ __global__ __launch_bounds__(GL_WAVES * 64) void group_linear_kernel(GLArgs a) {
 #pragma unroll
   for (int i = 0; i < NIN; ++i)
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) xn[i][kc] = ld_frag(xin[i] + kc * 16);
-  for (int g = 0; g < a.groups; ++g) {
+    for (int kc = 0; kc < 4; ++kc) xn[i][kc] = ld_frag(xin[i] + gbeg * GL_HD + kc * 16);
+  for (int g = gbeg; g < gend; ++g) {
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) xf[i][kc] = xn[i][kc];
-    if (g + 1 < a.groups) {
+    if (g + 1 < gend) {
 #pragma unroll
       for (int i = 0; i < NIN; ++i)
 #pragma unroll
@@ -132,7 +139,9 @@ extern "C" int segclip_group_linear64(const void* const* in, const int64_t* ld_i
       a.W[i][o] = (const bf16_t*)p;
     }
   a.M = M; a.groups = groups;
-  const dim3 grid((unsigned)cdiv(M, GL_WAVES * GL_ROWS)), block(GL_WAVES * 64);
+  static const int gsplit_env = [] { const char* e = getenv("SEGCLIP_GL64_GSPLIT"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : v; }();
+  const int gsplit = gsplit_env < groups ? gsplit_env : groups;
+  const dim3 grid((unsigned)cdiv(M, GL_WAVES * GL_ROWS), (unsigned)gsplit), block(GL_WAVES * 64);
   if (n_in == 1 && n_out == 1) hipLaunchKernelGGL((group_linear_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, a);
   else if (n_in == 1) hipLaunchKernelGGL((group_linear_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((group_linear_kernel<2, 1>), grid, block, 0, (hipStream_t)stream, a);
