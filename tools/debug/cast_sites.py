@@ -1,34 +1,25 @@
-"""Who launches the cast kernels of a step?  (monkeypatched ops.p_cast / p_cast_into: caller line + shape, one step)"""
-import os, sys, collections, traceback
+"""Which ops.p_cast / p_cast_into calls does one training step make, how large are they and who asked (bf16 mode, B = 256)?"""
+import os, sys, traceback, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import torch
-import segclip_amd
+import torch, segclip_amd
 from segclip_amd import synth, ops
-dev = torch.device("cuda", 0)
-spec = synth.SPECS["vitb16"]
 segclip_amd.set_compute_dtype(torch.bfloat16)
-torch.manual_seed(1234)
-model, targs = synth.build_model(spec, {}, rank=0, world_size=1, device=dev)
-model.clip.visual.conv1.weight.requires_grad_(False)
-model.clip.visual.positional_embedding.requires_grad_(False)
-batch = synth.synthetic_batch(spec, 256, seed=100, device=dev, with_seg=False)
+spec = synth.SPECS["vitb16"]
+model, _ = synth.build_model(spec, {}, device="cuda")
+batch = synth.synthetic_batch(spec, 256, seed=1, device="cuda")
 def step():
-    model.zero_grad(set_to_none=True)
-    model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"]).backward()
+    for p in model.parameters(): p.grad = None
+    loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"])
+    loss.backward()
 for _ in range(2): step()
-cnt = collections.Counter()
-orig, orig_into = ops.p_cast, ops.p_cast_into
-def site():
-    for f in reversed(traceback.extract_stack()[:-2]):
-        if "cast_sites" not in f.filename:
-            return f"{os.path.basename(f.filename)}:{f.lineno} {f.name}"
-def p_cast(t, dtype):
-    if t.dtype != dtype: cnt[(site(), tuple(t.shape), str(t.dtype).split('.')[-1] + "->" + str(dtype).split('.')[-1])] += 1
-    return orig(t, dtype)
-def p_cast_into(x, out):
-    cnt[(site(), tuple(x.shape), "into")] += 1
-    return orig_into(x, out)
-ops.p_cast, ops.p_cast_into = p_cast, p_cast_into
-step(); torch.cuda.synchronize()
-for (s, shape, kind), c in sorted(cnt.items(), key=lambda kv: -kv[1] * torch.Size(kv[0][1]).numel()):
-    print(f"{c:3d} x {kind:22s} {str(shape):24s} {s}")
+rec = collections.Counter()
+orig = ops.p_cast
+def spy(x, dt):
+    fr = [f for f in traceback.extract_stack()[:-1] if "segclip_amd" in f.filename][-2:]
+    rec[(tuple(x.shape), str(x.dtype).replace("torch.", ""), str(dt).replace("torch.", ""), " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(fr)))] += 1
+    return orig(x, dt)
+ops.p_cast = spy
+step()
+torch.cuda.synchronize()
+for (shape, sd, dd, who), n in sorted(rec.items(), key=lambda kv: -kv[1] * torch.Size(kv[0][0]).numel()):
+    print(f"{n:3d}x {str(shape):24s} {sd:9s}->{dd:9s} {torch.Size(shape).numel() * n / 1e6:8.1f} M elems  {who}")
