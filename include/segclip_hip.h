@@ -481,7 +481,7 @@ typedef struct segclip_wgrad_item {
   int64_t M, N, ld_dy, ld_x, ld_dw;
 } segclip_wgrad_item;
 int segclip_wgrad_group_splits(int64_t tiles, int64_t ksteps);
-/* the time model behind that choice (microseconds on MI355X: rounds of 256 workgroups x (K loop + output) + the partial tiles
+/* the time model behind that choice (microseconds on MI355X, fitted to profiles/r04_wgrad_group.txt: rounds of 256 workgroups x (K loop + output) + the partial tiles
  * written and read back); callers use it to decide how many blocks to group */
 double segclip_wgrad_group_model_us(int64_t tiles, int64_t ksteps, int splits);
 size_t segclip_wgrad_group_ws_bytes(const segclip_wgrad_item* items, int n, int splits);

@@ -983,13 +983,14 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
 void segclip_pq_launch_group(dim3, hipStream_t, const void*, const void*);
 
 // K ranges for a group of `tiles` 256x256 output tiles over `ksteps` 64-row K steps: the count that minimises the modelled time
-//   ceil(tiles * s / 256) rounds x (K loop of ksteps / s steps at ~1.26 us + ~5 us of prologue / output) + the fp32 partial tiles
+//   ceil(tiles * s / 256) rounds x (K loop of ksteps / s steps at ~1.63 us - the k-strided operand layout, fitted to
+//   profiles/r04_wgrad_group.txt - + ~5 us of prologue / output) + the fp32 partial tiles
 //   written and read back when s > 1 (~0.075 us each, device-wide)
 extern "C" double segclip_wgrad_group_model_us(int64_t tiles, int64_t ksteps, int splits) {
   if (tiles < 1 || ksteps < 1 || splits < 1) return 0.0;
   const int64_t per = cdiv(ksteps, splits);
   const double rounds = (double)cdiv(tiles * splits, 256);
-  return rounds * (per * 1.26 + 5.0) + (splits > 1 ? tiles * splits * 0.075 : 0.0);
+  return rounds * (per * 1.63 + 5.0) + (splits > 1 ? tiles * splits * 0.075 : 0.0);
 }
 extern "C" int segclip_wgrad_group_splits(int64_t tiles, int64_t ksteps) {
   if (tiles < 1 || ksteps < 1) return 1;
