@@ -21,8 +21,10 @@ wgrad_group_blocks : bf16 mode, inside ResStackFn: the weight gradients of up to
                 launch (ops.WgradGroup / segclip_wgrad_group) with few K ranges instead of 4 launches per block with 7-28 K
                 ranges each (64 MB of fp32 partial tiles per gradient); the partition of a stack into groups minimises the
                 library's time model.  1 = one launch per gradient (the round-3 behaviour).  Env SEGCLIP_WGRAD_GROUP.
-wgrad_group_blocks_dist : the same limit while GradSync bucket slots are active (world size > 1): short groups, so that
-                the bucket exchanges keep overlapping with the backward pass
+wgrad_group_blocks_dist : the same limit while GradSync bucket slots are active (world size > 1).  Default = the single-GPU
+                value: on one rank through the N>1 path a cap of 3 blocks costs 0.8 ms per step (39.9 vs 39.1 ms), while the
+                largest group (7 vision blocks, 200 MB of gradients) still has 3 blocks of backward (~6 ms) to hide its
+                exchange behind; lower it (env SEGCLIP_WGRAD_GROUP_DIST) if a real multi-GPU run shows exposed exchanges.
 trust_weight_shadows : False: every training forward re-casts all GEMM weights to bf16 (one multi-tensor launch);
                 True: only weights whose autograd version changed (set per model by train.prep_optimizer when the
                 fused optimizer maintains the bf16 copies itself)
@@ -61,7 +63,7 @@ _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=Fa
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
                  text_after_blocks=4,
-                 wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=3)
+                 wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP_DIST", "12")))
 _tls = threading.local()
 
 
