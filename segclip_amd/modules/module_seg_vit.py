@@ -2,6 +2,8 @@
 SemanticLearnerModule (learnable-center aggregation), ReconstructLayer, SegViT."""
 from collections import OrderedDict
 
+import os
+
 import torch
 from torch import nn
 from torch.nn.parameter import Parameter
@@ -66,6 +68,10 @@ class ResidualAttentionBlock(nn.Module):
                                     config.compute_dtype)
 
 
+# one autograd node per cross-attention block (ops.CrossBlockFn); SEGCLIP_CROSS_FUSED=0: the op-by-op composition
+_CROSS_FUSED = os.environ.get("SEGCLIP_CROSS_FUSED", "1") != "0"
+
+
 class CrossAttentionBlock(nn.Module):
     """modules/module_seg_vit.py:199-218: q += MHA(ln_x q, ln_k kv, ln_k kv); q += mlp(ln_2 q)."""
 
@@ -85,6 +91,11 @@ class CrossAttentionBlock(nn.Module):
         B, G, D = q.shape
         ad = config.compute_dtype
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        if kn_buf is not None and _CROSS_FUSED:
+            return ops.CrossBlockFn.apply(q, kn_buf, self.ln_x.weight, self.ln_x.bias, self.ln_k.weight, self.ln_k.bias, w, b,
+                                          self.attn.out_proj.weight, self.attn.out_proj.bias, self.ln_2.weight, self.ln_2.bias,
+                                          self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias,
+                                          self.n_head, config.cross_mode, (self.ln_x.eps, self.ln_k.eps, self.ln_2.eps), ad)[0]
         qn = self.ln_x(q)
         if kn_buf is not None:
             kn = ops.layer_norm_into(kn_buf, k, self.ln_k.weight, self.ln_k.bias, self.ln_k.eps, 0)

@@ -1301,6 +1301,110 @@ class CrossInProjAttnFn(Function):
         return dxq.view(B, G, D), dxk.view(B, S, D), dw, db, None, None, None, None, None, None
 
 
+class CrossBlockFn(Function):
+    """One CrossAttentionBlock of the learnable-center stage (reference modules/module_seg_vit.py:199-218) as ONE autograd node:
+        q1 = q + out_proj(MHA(ln_x q, ln_k kv, ln_k kv)),  kv = cat([q, tokens]);   q2 = q1 + c_proj(QuickGELU(c_fc(ln_2 q1)))
+    q (B, G, D) fp32; kn_buf (B, S, D) in the compute dtype whose rows [G, S) of every sample already hold ln_k(tokens)
+    (LayerNormMultiFn) - rows [0, G) are written here, in place (ln_k q).  The block is 8 center rows per sample: every
+    kernel is a few microseconds, so the node count is the cost - as separate LinearFn / LayerNormFn nodes its backward was
+    ~45 launches (a split-K combine, a bias column sum and its reduction per Linear, a reduction per LayerNorm, an add per
+    residual branch); here the residual adds ride in the LayerNorm backwards, the bias gradients come out of them / the
+    attention backward / the c_proj data gradient, and every trailing reduction joins ONE queue (2 launches).
+    Returns (q2, kn_buf); the gradient of kn_buf covers all S rows (its consumer reads the token rows only)."""
+
+    NPARAM = 14
+
+    @staticmethod
+    def forward(ctx, q, kn_buf, lnxw, lnxb, lnkw, lnkb, w_in, b_in, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr,
+                n_head, mode, eps, act_dtype):
+        B, G, D = q.shape
+        S = kn_buf.shape[1]
+        M, hd, F4 = B * G, D // n_head, wfc.shape[0]
+        act = ACT_QUICK_GELU
+        for w in (lnxw, lnxb, lnkw, lnkb, w_in, b_in, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr):
+            sl = _slot_of(w)
+            if sl is not None:
+                sl.note_forward_use()
+        q2d = q.contiguous().view(M, D)
+        kn2d = kn_buf.view(B * S, D)
+        qn, mx, rx = p_ln_fwd(q2d, lnxw, lnxb, eps[0], act_dtype)
+        _, mk, rk = p_ln_fwd(q2d, lnkw, lnkb, eps[1], act_dtype, out=kn2d, seg=(G, S, 0))
+        ctx.mark_dirty(kn_buf)
+        wc, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (w_in, wo, wfc, wpr))
+        bd = b_in.detach()
+        qp = p_linear(qn, wc[:D], bd[:D])[0]
+        kv = p_linear(kn2d, wc[D:], bd[D:])[0]
+        o = torch.empty_like(qp)
+        ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
+        ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd), False, 0, 0, D)
+        stats = p_attn_fwd(ad, qp)
+        q1 = p_linear(o, wo_c, bo, residual=q2d, out_dtype=torch.float32)[0]
+        z, m2, r2 = p_ln_fwd(q1, ln2w, ln2b, eps[2], act_dtype)
+        h, u = p_linear(z, wfc_c, bfc, act=act, want_aux=True, aux_kind=_aux_kind(act_dtype, act, M, F4))
+        q2 = p_linear(h, wpr_c, bpr, residual=q1, out_dtype=torch.float32)[0]
+        # (kn_buf itself, not its 2-D view: a view made here of a tensor this node marks dirty may not be saved)
+        ctx.save_for_backward(q2d, lnxw, mx, rx, qn, lnkw, mk, rk, kn_buf, wc, qp, kv, o, stats, wo_c, q1, ln2w, m2, r2, z, wfc_c, u, h,
+                              wpr_c)
+        ctx.cfg = (B, G, S, D, n_head, mode, act, act_dtype)
+        ctx.gslots = tuple(_slot_of(w) for w in (w_in, wo, wfc, wpr))
+        return q2.view(B, G, D), kn_buf
+
+    @staticmethod
+    def backward(ctx, dq2, _dbuf):
+        (q2d, lnxw, mx, rx, qn, lnkw, mk, rk, kn_buf, wc, qp, kv, o, stats, wo_c, q1, ln2w, m2, r2, z, wfc_c, u, h,
+         wpr_c) = ctx.saved_tensors
+        B, G, S, D, n_head, mode, act, act_dtype = ctx.cfg
+        kn2d = kn_buf.detach().view(B * S, D)
+        M, hd, F4 = B * G, D // n_head, wfc_c.shape[0]
+        bf = act_dtype == torch.bfloat16
+        s_in, s_o, s_fc, s_pr = ctx.gslots
+        g = dq2.contiguous().view(M, D)
+        if g.dtype != torch.float32:
+            g = p_cast(g, torch.float32)
+        g16 = p_cast(g, act_dtype) if bf else g
+        rq = ReduceQueue()
+        # ---- MLP
+        du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
+                           aux_kind=2 if u.dtype == torch.uint8 else _aux_kind(act_dtype, act), defer=rq)
+        dwpr = p_wgrad(g16, h, out=_slot_out(s_pr, (D, F4)), defer=rq)
+        dz = p_dgrad(du, wfc_c, act_dtype)
+        dwfc = p_wgrad(du, z, out=_slot_out(s_fc, (F4, D)), defer=rq)
+        r = p_ln_bwd(dz, q1, ln2w, m2, r2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True, defer=rq)
+        dq1, dln2w, dln2b = r[0], r[1], r[2]
+        dq1_16 = r[3] if bf else dq1
+        dbpr = r[-1]                                             # colsum(g): the c_proj bias gradient
+        # ---- attention
+        do = p_dgrad(dq1_16, wo_c, act_dtype)
+        dwo = p_wgrad(dq1_16, o, out=_slot_out(s_o, (D, D)), defer=rq)
+        ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
+        ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd), False, 0, 0, D)
+        dqp, dkv = torch.empty_like(qp), torch.empty_like(kv)
+        part = _empty((B, 3 * D), torch.float32, do) if bf else None
+        p_attn_bwd(ad, stats, do, dqp, dkv, dkv, (G * D, D), ks, ks, (G * D, D), 0, 0, D, colsum_part=part)
+        dqn = p_dgrad(dqp, wc[:D], act_dtype)
+        dkn = p_dgrad(dkv, wc[D:], act_dtype)
+        dw_in = _slot_out(s_in, (3 * D, D))
+        if dw_in is None:
+            dw_in = _empty((3 * D, D), torch.float32, do)
+        p_wgrad(dqp, qn, out=dw_in[:D], defer=rq)
+        p_wgrad(dkv, kn2d, out=dw_in[D:], defer=rq)
+        db_in = _empty((3 * D,), torch.float32, do)
+        if part is not None:
+            rq.add_rows(part, B, 3 * D, 3 * D, (db_in,), 3 * D)
+        else:
+            p_colsum(dqp, out=db_in[:D])
+            p_colsum(dkv, out=db_in[D:])
+        # ---- the two LayerNorms of q: ln_x (dres = dq1: the residual branch; its column sums = the out_proj bias gradient),
+        # then ln_k's center rows (dres = what the first one produced)
+        r = p_ln_bwd(dqn, q2d, lnxw, mx, rx, dres=dq1, dx_dtype=torch.float32, want_dres_colsum=True, defer=rq)
+        dq_a, dlnxw, dlnxb, dbo = r[0], r[1], r[2], r[-1]
+        r = p_ln_bwd(dkn, q2d, lnkw, mk, rk, dres=dq_a, dx_dtype=torch.float32, defer=rq, seg=(G, S, 0))
+        dq, dlnkw, dlnkb = r[0], r[1], r[2]
+        rq.flush()
+        return (dq.view(B, G, D), dkn.view(B, S, D), dlnxw, dlnxb, dlnkw, dlnkb, dw_in, db_in, dwo, dbo, dln2w, dln2b, dwfc, dbfc,
+                dwpr, dbpr, None, None, None, None)
+
+
 class PatchEmbedFn(Function):
     """conv1 (16x16/16, no bias) as im2col + GEMM with the positional table fused as the epilogue
     residual (modules/module_clip_vtransformer.py:56-64).  The CLS row the reference prepends is

@@ -1116,3 +1116,51 @@ def test_patch_embedding_one_gemm_matches_batched_form():
     close(outs[BF][0], outs[F32][0], 2e-2, 2e-2, "patch embedding")
     close(outs[BF][1], outs[F32][1], 3e-2, 3e-2 * float(outs[F32][1].abs().max()), "d conv1")
     close(outs[BF][2], outs[F32][2], 1e-5, 1e-5, "d pos")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("mode", ["t18", "intended"])
+def test_cross_attention_block_as_one_node(dtype, mode, monkeypatch):
+    """ops.CrossBlockFn (a CrossAttentionBlock of the center stage, reference modules/module_seg_vit.py:199-218, as ONE autograd
+    node with a hand-scheduled backward) against the same module run op by op (LayerNormFn / CrossInProjAttnFn / LinearFn
+    nodes): output, the gradients of the centers and of the key/value buffer's token rows, and all 14 parameter gradients."""
+    import segclip_amd
+    from segclip_amd.modules import module_seg_vit as msv
+    B, G, T, D, H = 4, 8, 56, 256, 4
+    S = G + T
+    torch.manual_seed(5)
+    blk = msv.CrossAttentionBlock(D, H).to(DEV)
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, std=0.05) if p.dim() > 1 else torch.nn.init.normal_(p, mean=1.0 if "ln" in "" else 0.0, std=0.1)
+    for ln in (blk.ln_x, blk.ln_k, blk.ln_2):
+        ln.weight.data.add_(1.0)
+    q0, tok0 = rnd(B, G, D, seed=401), rnd(B, T, D, seed=402)
+    gout = rnd(B, G, D, seed=403)
+    res = {}
+    segclip_amd.set_compute_dtype(dtype)
+    segclip_amd.set_cross_mode(mode)
+    try:
+        for fused in (False, True):
+            monkeypatch.setattr(msv, "_CROSS_FUSED", fused)
+            for p in blk.parameters():
+                p.grad = None
+            q = q0.clone().requires_grad_()
+            tok = tok0.clone().requires_grad_()
+            tokn = ops.layer_norm(tok, blk.ln_k.weight, blk.ln_k.bias, blk.ln_k.eps, dtype)
+            buf = torch.cat([torch.zeros(B, G, D, device=DEV, dtype=dtype), tokn], 1)
+            out = blk(q, q, kn_buf=buf)
+            out.backward(gout)
+            res[fused] = (out.detach().clone(), q.grad.clone(), tok.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()})
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
+        segclip_amd.set_cross_mode("t18")
+    rt = 1e-4 if dtype == F32 else 3e-2
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    assert rel(res[True][0], res[False][0]) <= rt, ("out", rel(res[True][0], res[False][0]))
+    assert rel(res[True][1], res[False][1]) <= rt, ("dq", rel(res[True][1], res[False][1]))
+    assert rel(res[True][2], res[False][2]) <= rt, ("dtokens", rel(res[True][2], res[False][2]))
+    for n in res[False][3]:
+        e = rel(res[True][3][n], res[False][3][n])
+        assert e <= rt, (n, e)

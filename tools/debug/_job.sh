@@ -1,7 +1,2 @@
-mkdir -p gpurun_out/r04
-b() { local name=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/r04/bench_$name.json 2> gpurun_out/r04/bench_$name.err; echo "$name: $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/r04/bench_$name.json)"; }
-b plain_ref --no-cpu-baseline --no-roofline
-b dist --no-cpu-baseline --no-roofline --force-dist
-b dist_bf16wire --no-cpu-baseline --no-roofline --force-dist --wire bf16
-b plain_ref2 --no-cpu-baseline --no-roofline
-timeout 1200 python -m pytest tests/test_dist_gpu.py tests/test_train_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error" | tail -3
+mkdir -p gpurun_out/r04t
+for i in 1 2; do for v in 0 1; do SEGCLIP_CROSS_FUSED=$v python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --batch 64 2>&1 | grep '"metric"' | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/B64 cross_fused=$v /" | tee -a gpurun_out/r04t/ab64.txt; done; done
