@@ -42,7 +42,7 @@ s = setnote(s, "same, global batch 2048 on one GPU (`--global-batch 2048`)",
             f"round 3: 6622 / 309.3; GEMM {rf('gb2048')['achieved']:.0f} TF/s over all launches ({rf('gb2048')['frac']:.3f}); `step_frac` {rf('gb2048')['step_frac']:.3f}")
 s = setnote(s, "full SegCLIP loss (configs[3])", f"round 3: 3798 / 67.4; `step_frac` {rf('full_loss')['step_frac']:.3f}")
 s = setnote(s, "through the N>1 code path on one rank (RCCL group + GradSync, fp32 wire; `--force-dist`)",
-            f"{dist_delta:+.1f} ms against {ref:.2f} ms for the default configuration on the same (second) box: the 1-rank exchange, hooks and bucket slots; bf16 wire: {ms('dist_bf16wire')}")
+            f"{dist_delta:+.1f} ms against {ref:.2f} ms for the default configuration measured right before and after on the same box: the 1-rank exchange, hooks and bucket slots; bf16 wire: {ms('dist_bf16wire')}")
 s = setnote(s, "ViT-L/14 336^2, B=128 (configs[4], `--spec vitl14_336`; `--attn-fp8 auto` = off)",
             f"round 3 (another box): 1308 / 1281; `step_frac` {rf('vitl14')['step_frac']:.3f}; GEMM {rf('vitl14')['achieved']:.0f} TF/s over all launches ({rf('vitl14')['frac']:.3f})")
 s = setnote(s, "per-GPU batch 64 / 128 / 512", "B=64 is host-bound (launch enqueue, un-profiled)")
@@ -61,7 +61,7 @@ s = setnote(s, "same-node yardstick: PyTorch-ROCm eager, bf16 autocast + SDPA, s
             f"`profiles/r04_eager_ab.json`: this build is {E['speedup_vs_eager']}× eager on the same box; per-class rows: torch layer_norm fwd / bwd 85 / 223 µs at 50176×768 (here 44 / 131), SDPA fwd / bwd "
             "177 / 832 µs at T = 196 (here 113 / 312)", (round(E["pairs_per_s"]), f"{E['ms_per_step']:.1f}"))
 s = setnote(s, "same through the N>1 path, 1-rank RCCL group, GradSync fp32 wire (`--force-dist`)",
-            f"{dist_delta:+.1f} ms against {ref:.2f} ms plain on the same (second) box (round 3: +1.0); bf16 wire {ms('dist_bf16wire')}")
+            f"{dist_delta:+.1f} ms against {ref:.2f} ms plain right before / after on the same box (round 3: +1.0); bf16 wire {ms('dist_bf16wire')}")
 s = setnote(s, "contrastive only, global batch 2048 on one GPU (`--global-batch 2048`, SURVEY §8d strong-scaling base)",
             f"`step_frac` {rf('gb2048')['step_frac']:.3f}; GEMM {rf('gb2048')['achieved']:.0f} TF/s over all launches (`frac` {rf('gb2048')['frac']:.3f}); round 3: 6622 / 309.3")
 s = setnote(s, "full SegCLIP loss (configs[3], `--full-loss`)", f"144.07 GF per pair: `step_frac` {rf('full_loss')['step_frac']:.3f}; round 3: 3798 / 67.4")

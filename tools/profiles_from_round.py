@@ -32,7 +32,7 @@ for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base o
                 ("resid_bf16", "--resid bf16: bf16 residual stream between the blocks of a tower (config.bf16_resid, opt-in)"),
                 ("dist", "--force-dist: N>1 code path (RCCL group, GradSync fp32 wire) on one rank"), ("dist_bf16wire", "--force-dist --wire bf16"),
                 ("vitl14", "--spec vitl14_336 --batch 128 --attn-fp8 off (BASELINE configs[4], bf16 attention)"),
-                ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("plain_ref", "default configuration on the box of the `dist` / `dist_bf16wire` lines (they were re-measured on a second box after wgrad_group_blocks_dist changed)"),
+                ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("plain_ref", "default configuration right before the `dist` / `dist_bf16wire` lines (same box)"),
                 ("plain_ref2", "the same, after the dist lines"),
                 ("b64", "--batch 64"), ("b128", "--batch 128"), ("b512", "--batch 512"),
                 ("wgrad_single_a", "SEGCLIP_WGRAD_GROUP=1 (one launch per weight gradient), same box, --steps 30"),
