@@ -68,7 +68,7 @@ s = setnote(s, "full SegCLIP loss (configs[3], `--full-loss`)", f"144.07 GF per 
 s = setnote(s, "ViT-L/14 336², B=128 (configs[4], `--spec vitl14_336`; `--attn-fp8 auto` = off)",
             f"`step_frac` {rf('vitl14')['step_frac']:.3f}; GEMM {rf('vitl14')['achieved']:.0f} TF/s ({rf('vitl14')['frac']:.3f}); round 3 (another box): 1308 / 1281")
 a = s.index("Per step, kernel time by class (`profiles/r04_bench_line.json`")
-b = s.index("; 644 dispatches per step", a)
+b = s.index("; 600 dispatches per step", a)
 tab = {}
 for l in open(f"{ROOT}/profiles/r04_bench_kernel_stats.txt"):
     m = re.match(r"(.*?)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", l)
