@@ -170,9 +170,19 @@ class WgradGroup:
             rq.flush()
 
 
+_PLAN_CACHE = {}
+
+
 def wgrad_group_plan(nblk, tiles_blk, ksteps, gmax):
     """Sizes (in blocks, in backward order) of the weight-gradient groups of a stack of nblk equal blocks: the partition with
     the smallest modelled time (segclip_wgrad_group_model_us at the K-range count the library would choose)."""
+    key = (int(nblk), int(tiles_blk), int(ksteps), int(gmax))
+    if key not in _PLAN_CACHE:
+        _PLAN_CACHE[key] = _wgrad_group_plan(*key)
+    return list(_PLAN_CACHE[key])
+
+
+def _wgrad_group_plan(nblk, tiles_blk, ksteps, gmax):
     lib = L.load()
     gmax = max(1, min(int(gmax), nblk, 48 // 4))
     cost = [0.0] * (gmax + 1)
