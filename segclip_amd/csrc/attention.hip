@@ -614,6 +614,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 }
 
 #include "attention_sp.inc"
+#include "attention_pf.inc"
 #include "attention_stream.inc"
 #include "attention_fp8.inc"
 
@@ -664,6 +665,32 @@ bool bf16_ok(const segclip_attn_desc* d) {
   return d->hd % 8 == 0 && d->hd <= 64;
 }
 
+
+// persistent forward (attention_pf.inc): launch instance <NT, CAUSAL> on a grid of as many workgroups as the device holds
+template <int NT, bool CAUSAL, int ABL = 0>
+int launch_fwd_pf(const FwdArgs& a, int nitems, hipStream_t stream) {
+  int dev = 0;
+  SEGCLIP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "attn_fwd: cannot query the current device");
+  static int grid_dev[64] = {};
+  const size_t lds = fwd_pf_lds_bytes(NT);
+  if (grid_dev[dev] == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_pf_kernel<NT, CAUSAL, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SEGCLIP_REQUIRE(e == hipSuccess, "attn_fwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    int ncu = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_fwd_pf_kernel<NT, CAUSAL, ABL>, NT * 64, lds) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_GRID"); return e ? atoi(e) : 0; }();
+    if (grid_env > 0) per_cu = grid_env;
+    grid_dev[dev] = ncu * per_cu;
+  }
+  const int grid = nitems < grid_dev[dev] ? nitems : grid_dev[dev];
+  hipLaunchKernelGGL((attn_fwd_pf_kernel<NT, CAUSAL, ABL>), dim3((unsigned)grid), dim3(NT * 64), lds, stream, a, nitems);
+  SEGCLIP_CHECK_LAUNCH("attn_fwd_pf");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" size_t segclip_attn_stats_bytes(const segclip_attn_desc* d) {
@@ -706,6 +733,33 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
       return 0;
     }
     const int tiles = (int)cdiv(d->Tq, 32);
+    // self-attention of 65..96 / 161..224 tokens: the persistent LDS-DMA kernel (attention_pf.inc); SEGCLIP_ATTN_FWD_PF=0
+    // falls back to one workgroup per (batch, head)
+    static const int use_pf = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_PF"); return e ? atoi(e) : 1; }();
+    static const int pf_dbg = [] { const char* e = getenv("SEGCLIP_ATTN_PF_DBG"); return e ? atoi(e) : 0; }();
+    if (use_pf) a.staged = pf_dbg;
+    if (use_pf && d->Tq == d->Tk && !(d->flags & SEGCLIP_ATTN_FP8) && (tiles == 3 || tiles == 6 || tiles == 7)) {
+      const int nitems = (int)(d->B * d->H);
+      if (d->causal) {
+        if (tiles == 3) return launch_fwd_pf<3, true>(a, nitems, stream);
+        if (tiles == 6) return launch_fwd_pf<6, true>(a, nitems, stream);
+        return launch_fwd_pf<7, true>(a, nitems, stream);
+      }
+#ifdef SEGCLIP_EXPERIMENTS
+      static const int pf_abl = segclip_ablation_env("SEGCLIP_ATTN_PF_ABL");
+      if (tiles == 7) switch (pf_abl) {
+        case 1: return launch_fwd_pf<7, false, 1>(a, nitems, stream);
+        case 2: return launch_fwd_pf<7, false, 2>(a, nitems, stream);
+        case 3: return launch_fwd_pf<7, false, 3>(a, nitems, stream);
+        case 4: return launch_fwd_pf<7, false, 4>(a, nitems, stream);
+        case 5: return launch_fwd_pf<7, false, 5>(a, nitems, stream);
+        default: break;
+      }
+#endif
+      if (tiles == 3) return launch_fwd_pf<3, false>(a, nitems, stream);
+      if (tiles == 6) return launch_fwd_pf<6, false>(a, nitems, stream);
+      return launch_fwd_pf<7, false>(a, nitems, stream);
+    }
     const int nw = tiles < 8 ? tiles : (tiles <= 8 ? 8 : (int)cdiv(tiles, cdiv(tiles, 8)));
     SEGCLIP_REQUIRE(d->B * d->H <= 65535, "attn_fwd: B*H too large");
     if (d->flags & SEGCLIP_ATTN_FP8) {

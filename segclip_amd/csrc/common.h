@@ -43,11 +43,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// two fp32 -> packed bf16x2 with the gfx950 hardware converter (round-to-nearest-even; no builtin exists)
+// two fp32 -> packed bf16x2 with the gfx950 hardware converter v_cvt_pk_bf16_f32 (round-to-nearest-even).  Written as a
+// vector conversion, NOT as inline asm (rounds 1-4): hipcc selects the same instruction, and - unlike for an asm statement -
+// pads its hazards.  gfx950 needs one wait state between a transcendental (v_exp_f32, v_rcp_f32 ...) and a VALU reading its
+// result; with the asm form hipcc scheduled `v_exp_f32 v1, v1` directly in front of `v_cvt_pk_bf16_f32 v64, v0, v1` (72
+// places in attention.hip alone) and the converter read the stale register: wrong P values on some code placements
+// (found round 5 through the causal instance of the persistent attention forward).
+typedef __bf16 segclip_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float segclip_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  const segclip_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, segclip_bf16x2_t));
 }
 
 template <typename T> struct io;
