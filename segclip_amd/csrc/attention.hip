@@ -736,8 +736,6 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     // self-attention of 65..96 / 161..224 tokens: the persistent LDS-DMA kernel (attention_pf.inc); SEGCLIP_ATTN_FWD_PF=0
     // falls back to one workgroup per (batch, head)
     static const int use_pf = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_PF"); return e ? atoi(e) : 1; }();
-    static const int pf_dbg = [] { const char* e = getenv("SEGCLIP_ATTN_PF_DBG"); return e ? atoi(e) : 0; }();
-    if (use_pf) a.staged = pf_dbg;
     if (use_pf && d->Tq == d->Tk && !(d->flags & SEGCLIP_ATTN_FP8) && (tiles == 3 || tiles == 6 || tiles == 7)) {
       const int nitems = (int)(d->B * d->H);
       if (d->causal) {
@@ -753,6 +751,7 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
         case 3: return launch_fwd_pf<7, false, 3>(a, nitems, stream);
         case 4: return launch_fwd_pf<7, false, 4>(a, nitems, stream);
         case 5: return launch_fwd_pf<7, false, 5>(a, nitems, stream);
+        case 6: return launch_fwd_pf<7, false, 6>(a, nitems, stream);
         default: break;
       }
 #endif

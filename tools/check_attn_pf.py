@@ -38,11 +38,15 @@ if __name__ == "__main__":
         for k in res[0]:
             a, b = res[0][k], res[1][k]
             eq = torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())
-            if not eq:
+            # the persistent kernel takes the row maximum over 64 keys at a time: bf16 roundings of P differ -> tolerance
+            tol = 2e-2 if k.startswith("o") else 2e-5
+            fin = ~(a.isinf() & b.isinf() & (a == b))
+            close = bool(a.isnan().sum() == b.isnan().sum()) and bool(((a - b)[fin].abs() <= tol).all())
+            if eq or close:
+                print(f"ok {k} {tuple(a.shape)} max |d| {float((a - b)[fin].abs().max()) if fin.any() else 0.0:.3g}")
+            elif not eq:
                 bad += 1
                 d = (a - b).abs()
                 print(f"MISMATCH {k}: max |d| {float(d[~d.isnan()].max()) if (~d.isnan()).any() else float('nan')}, nan in new {int(b.isnan().sum())} old {int(a.isnan().sum())}, differing {int((a != b).sum())} of {a.numel()}")
-            else:
-                print(f"ok {k} {tuple(a.shape)}")
-        print("ALL EQUAL" if bad == 0 else f"{bad} MISMATCHES")
+        print("ALL CLOSE" if bad == 0 else f"{bad} MISMATCHES")
         sys.exit(1 if bad else 0)
