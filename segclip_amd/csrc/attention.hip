@@ -671,22 +671,29 @@ template <int NT, bool CAUSAL, int ABL = 0>
 int launch_fwd_pf(const FwdArgs& a, int nitems, hipStream_t stream) {
   int dev = 0;
   SEGCLIP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "attn_fwd: cannot query the current device");
-  static int grid_dev[64] = {};
-  const size_t lds = fwd_pf_lds_bytes(NT);
-  if (grid_dev[dev] == 0) {
+  static bool attr_set[64] = {};
+  static int ncu_dev[64] = {};
+  static int per_cu_cache[64][33] = {};                    // by (device, key tile rows / 8)
+  const size_t lds = fwd_pf_lds_bytes(NT, a.Tq);
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_pf_kernel<NT, CAUSAL, ABL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SEGCLIP_REQUIRE(e == hipSuccess, "attn_fwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    int ncu = 0, per_cu = 0;
+    int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_fwd_pf_kernel<NT, CAUSAL, ABL>, NT * 64, lds) != hipSuccess || per_cu < 1)
-      per_cu = 1;
-    static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_GRID"); return e ? atoi(e) : 0; }();
-    if (grid_env > 0) per_cu = grid_env;
-    grid_dev[dev] = ncu * per_cu;
+    ncu_dev[dev] = ncu;
+    attr_set[dev] = true;
   }
-  const int grid = nitems < grid_dev[dev] ? nitems : grid_dev[dev];
-  hipLaunchKernelGGL((attn_fwd_pf_kernel<NT, CAUSAL, ABL>), dim3((unsigned)grid), dim3(NT * 64), lds, stream, a, nitems);
+  int& per_cu = per_cu_cache[dev][pf_kv_rows(a.Tq) >> 3];
+  if (per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_pf_kernel<NT, CAUSAL, ABL>, (NT + 1) * 64, lds) != hipSuccess || n < 1) n = 1;
+    static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_GRID"); return e ? atoi(e) : 0; }();
+    per_cu = grid_env > 0 ? grid_env : n;
+  }
+  const int cap = ncu_dev[dev] * per_cu;
+  const int grid = nitems < cap ? nitems : cap;
+  hipLaunchKernelGGL((attn_fwd_pf_kernel<NT, CAUSAL, ABL>), dim3((unsigned)grid), dim3((NT + 1) * 64), lds, stream, a, nitems);
   SEGCLIP_CHECK_LAUNCH("attn_fwd_pf");
   return 0;
 }
@@ -733,10 +740,11 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
       return 0;
     }
     const int tiles = (int)cdiv(d->Tq, 32);
-    // self-attention of 65..96 / 161..224 tokens: the persistent LDS-DMA kernel (attention_pf.inc); SEGCLIP_ATTN_FWD_PF=0
-    // falls back to one workgroup per (batch, head)
+    // self-attention of 65..96 / 161..200 tokens: the persistent kernel with a loader wave (attention_pf.inc);
+    // SEGCLIP_ATTN_FWD_PF=0 falls back to one workgroup per (batch, head)
     static const int use_pf = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_PF"); return e ? atoi(e) : 1; }();
-    if (use_pf && d->Tq == d->Tk && !(d->flags & SEGCLIP_ATTN_FP8) && (tiles == 3 || tiles == 6 || tiles == 7)) {
+    if (use_pf && d->Tq == d->Tk && !(d->flags & SEGCLIP_ATTN_FP8) && (tiles == 3 || tiles == 6 || tiles == 7) &&
+        fwd_pf_lds_bytes(tiles, (int)d->Tq) <= 160 * 1024) {
       const int nitems = (int)(d->B * d->H);
       if (d->causal) {
         if (tiles == 3) return launch_fwd_pf<3, true>(a, nitems, stream);
@@ -745,15 +753,8 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
       }
 #ifdef SEGCLIP_EXPERIMENTS
       static const int pf_abl = segclip_ablation_env("SEGCLIP_ATTN_PF_ABL");
-      if (tiles == 7) switch (pf_abl) {
-        case 1: return launch_fwd_pf<7, false, 1>(a, nitems, stream);
-        case 2: return launch_fwd_pf<7, false, 2>(a, nitems, stream);
-        case 3: return launch_fwd_pf<7, false, 3>(a, nitems, stream);
-        case 4: return launch_fwd_pf<7, false, 4>(a, nitems, stream);
-        case 5: return launch_fwd_pf<7, false, 5>(a, nitems, stream);
-        case 6: return launch_fwd_pf<7, false, 6>(a, nitems, stream);
-        default: break;
-      }
+      if (tiles == 7 && pf_abl == 4) return launch_fwd_pf<7, false, 4>(a, nitems, stream);
+      if (tiles == 7 && pf_abl == 5) return launch_fwd_pf<7, false, 5>(a, nitems, stream);
 #endif
       if (tiles == 3) return launch_fwd_pf<3, false>(a, nitems, stream);
       if (tiles == 6) return launch_fwd_pf<6, false>(a, nitems, stream);
