@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-leg", action="store_true",
+                    help="skip the legs behind the timed region: exact-f32 parity mode timed for 3 steps + bf16-vs-f32 agreement on "
+                         "injected noise (`parity_mode`, `bf16_vs_f32`), and the single-GPU global-batch-2048 point")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs (HBM bytes of the GEMM)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N>1 code path (RCCL group, GradSync, barriers) even with one rank: single-GPU check of it")
@@ -194,7 +197,8 @@ def respawn(a):
 def child_argv(a, steps, warmup):
     """bench.py command line of the same per-GPU workload on ONE GPU, without the roofline / CPU-baseline legs."""
     argv = [os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch", str(a.batch),
-            "--spec", a.spec, "--dtype", a.dtype, "--attn-fp8", a.attn_fp8, "--resid", a.resid, "--no-roofline", "--no-cpu-baseline"]
+            "--spec", a.spec, "--dtype", a.dtype, "--attn-fp8", a.attn_fp8, "--resid", a.resid, "--no-roofline", "--no-cpu-baseline",
+            "--no-parity-leg"]
     if a.full_loss:
         argv.append("--full-loss")
     return argv
@@ -246,13 +250,16 @@ def roofline_block(a, step, pairs_per_gpu, world, work, collective_free=True):
             return None
         n, fl, nb = work[kind]
         t = cl[cls]["time_per_step_ms"] * 1e-3
-        d = {"time_per_step_ms": cl[cls]["time_per_step_ms"], "launches_per_step": cl[cls]["launches_per_step"],
-             "avg_launch_us": cl[cls]["avg_launch_us"], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "unit": "TFLOP/s",
-             "frac": round(fl / t / 1e12 / PEAK_BF16_TF, 4), "algorithmic_gbytes_per_s": round(nb / t / 1e9, 1)}
+        d = {"time_per_step_ms": cl[cls]["time_per_step_ms"], "time_base": "sum_of_durations (two concurrent streams: may exceed ms_per_step)",
+             "launches_per_step": cl[cls]["launches_per_step"],
+             "avg_launch_us": cl[cls]["avg_launch_us"], "bound": "mfma", "achieved_per_launch": round(fl / t / 1e12, 1), "unit": "TFLOP/s",
+             "frac_per_launch": round(fl / t / 1e12 / PEAK_BF16_TF, 4), "algorithmic_gbytes_per_s": round(nb / t / 1e9, 1)}
         u = cl[cls].get("union_ms_per_step")
         if u:   # time during which at least one kernel of the class runs (two concurrent streams share the chip)
-            d.update(union_ms_per_step=u, achieved_union=round(fl / (u * 1e-3) / 1e12, 1),
-                     frac_union=round(fl / (u * 1e-3) / 1e12 / PEAK_BF16_TF, 4))
+            d.update(union_ms_per_step=u, achieved=round(fl / (u * 1e-3) / 1e12, 1),
+                     frac=round(fl / (u * 1e-3) / 1e12 / PEAK_BF16_TF, 4))
+        else:
+            d.update(achieved=d["achieved_per_launch"], frac=d["frac_per_launch"])
         return d
 
     def hbm(kind, cls):
@@ -276,16 +283,21 @@ def roofline_block(a, step, pairs_per_gpu, world, work, collective_free=True):
     tr = m["traffic"]
     return {"bound": "mfma", "kernel": "gemm_bf16_pq_kernel / gemm_bf16_pq_group_kernel / gemm_bf16_p8_kernel / gemm_bf16_dma_kernel (+gemm_bf16_kernel fallback), all launches of a step",
             "achieved": g["achieved"], "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": g["frac"],
+            "time_base": ("union: the time of a step during which at least one kernel of the class is running (both streams), "
+                          "the figure that stays below ms_per_step" if g.get("union_ms_per_step") else "sum_of_durations"),
+            "union_ms_per_step": g.get("union_ms_per_step"),
             "avg_launch_us": g["avg_launch_us"], "launches_per_step": g["launches_per_step"],
-            "time_per_step_ms": g["time_per_step_ms"],
-            "union_ms_per_step": g.get("union_ms_per_step"), "achieved_union": g.get("achieved_union"), "frac_union": g.get("frac_union"),
+            "sum_of_durations_ms_per_step": g["time_per_step_ms"],
+            "achieved_per_launch": g["achieved_per_launch"], "frac_per_launch": g["frac_per_launch"],
+            "gpu_busy_ms_per_step": m.get("union_all_ms_per_step"),
             "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(nb / n),
             "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_detail": tr,
             "source": f"kernel durations of a rocprofv3 --kernel-trace --stats child run of this workload on one GPU ({ksteps + kwarm} model "
                       "passes, text tower concurrent on its second stream as in the timed region); flops / bytes counted by the op layer",
-            "two_stream_note": "class times are sums of kernel durations on two concurrent streams: they may add up to more than ms_per_step "
-                               "(two GEMMs sharing the chip each take longer); union_ms_per_step / achieved_union / frac_union use the time "
-                               "during which at least one kernel of the class is running instead",
+            "two_stream_note": "achieved / frac = the class's flops over union_ms_per_step (merged kernel intervals of the class over both "
+                               "streams; <= ms_per_step by construction).  achieved_per_launch / frac_per_launch = flops per launch over the "
+                               "average launch duration = what `rocprofv3 --stats` prints (sum_of_durations_ms_per_step: two GEMMs sharing "
+                               "the chip each take longer, so this sum may exceed ms_per_step and counts the machine twice)",
             "all_kernels_ms_per_step": round(sum(v["time_per_step_ms"] for k, v in cl.items() if k != "startup_probe"), 3),
             "classes": classes, "step_frac": step_frac, "notes": m["notes"]}
 
@@ -420,6 +432,72 @@ def main():
     ms = elapsed / a.steps * 1e3
     pairs = a.batch * world * a.steps / elapsed
 
+    # ---- behind the timed region: the mode that meets north_star's 1e-3 / bit-exact bar, timed, and the
+    # agreement of the benchmarked bf16 mode with it on the same inputs and the same injected noise.  Every rank runs the
+    # same sequence (the steps contain the collectives); rank 0 reports.
+    parity_mode = bf16_vs_f32 = gb2048 = None
+    if not a.no_parity_leg and a.dtype == "bf16" and a.spec == "vitb16":
+        noise = synth.synthetic_noise(spec, a.batch, seed=100 + rank, device=dev)
+        items = [("gumbel", noise["gumbel_main"])]
+        if a.full_loss:
+            items += [("rand", noise["mask_noise"]), ("gumbel", noise["gumbel_mae"])]
+
+        def probe():
+            with segclip_amd.noise_injection(items):
+                l_ = step()
+            torch.cuda.synchronize()
+            return float(l_.detach()), model.last_logits[0].float().clone(), model.last_mid_states["hard_idx"].clone()
+
+        lb, tb, hb = probe()
+        segclip_amd.set_compute_dtype(torch.float32)
+        try:
+            lf, tf_, hf = probe()              # also the warm-up of the f32 kernels
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            dt = (time.perf_counter() - t1) / 3
+        finally:
+            segclip_amd.set_compute_dtype(torch.bfloat16)
+        parity_mode = {"dtype": "f32", "pairs_per_s": round(a.batch * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": 3,
+                       "note": "exact-f32 mode (v_mfma_f32_32x32x2_f32 GEMMs, fp32 activations): the mode the parity tests hold to "
+                               "1e-3 / bit-exact indices against the reference; same model, same batch"}
+        bf16_vs_f32 = {"d_loss": round(abs(lb - lf), 6), "max_dlogit": round(float((tb - tf_).abs().max()), 4),
+                       "hard_idx_agree": round(float((hb == hf).float().mean()), 5),
+                       "note": "benchmarked bf16 mode against the exact-f32 mode, same batch and injected Gumbel noise; bf16 does not "
+                               "meet the 1e-3 logit bar (disclosed in DESIGN.md 2)"}
+        del tb, tf_, hb, hf
+        if world == 1 and not a.full_loss and not a.global_batch and not a.force_dist and a.batch < 2048:
+            # the metric's literal N = 1 point: global batch 2048 on one GPU (SURVEY 8d strong-scaling base)
+            try:
+                big = synth.synthetic_batch(spec, 2048, seed=100, device=dev, with_seg=False)
+
+                def step_big():
+                    for p in params:
+                        p.grad = None
+                    l_ = net(big["input_ids"], big["segment_ids"], big["input_mask"], big["image"])
+                    l_.backward()
+                    return l_
+                step_big()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step_big()
+                torch.cuda.synchronize()
+                dtb = (time.perf_counter() - t1) / 3
+                gb2048 = {"pairs_per_s": round(2048 / dtb, 1), "ms_per_step": round(dtb * 1e3, 2), "steps": 3,
+                          "step_frac": round(2048 / dtb * GF_PER_PAIR[("vitb16", False)] / 1e3 / PEAK_BF16_TF, 4)}
+                del big
+                torch.cuda.empty_cache()
+                step()                      # back to the benchmarked shape before the roofline leg counts a step
+            except Exception as e:           # never lose the headline line over a secondary field
+                gb2048 = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+
     roofline = None
     if not a.no_roofline and a.dtype == "bf16":
         # EVERY rank runs the op-count pass (one more step: its collectives must be matched on all ranks - ADVICE r3: with
@@ -458,6 +536,7 @@ def main():
                           "residual_stream": ("bf16 between the blocks of a tower, fp32 at the tower boundaries"
                                               if (a.dtype == "bf16" and segclip_amd.config.bf16_resid) else "fp32"),
                           "cross_mode": segclip_amd.config.cross_mode, "loss": round(loss_val, 5)},
+               "parity_mode": parity_mode, "bf16_vs_f32": bf16_vs_f32, "global_batch_2048_single_gpu": gb2048,
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if multi:

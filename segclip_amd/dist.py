@@ -109,6 +109,8 @@ class GradSync(nn.Module):
         self._pass_id = 0
         self._steady_passes = 0      # synced backward passes since the layout was frozen
         self.stats = {"copies": 0, "zero_copy": 0, "buckets": 0, "verdicts": 0}
+        self._verdicts = []          # posted, not yet read agreement checks: (event, pinned host pair)
+        self.timeline = None         # set to [] to record (bucket, bytes, ready event) per exchange (tools/bucket_timeline.py)
         self._accumulated = False    # a no_sync() backward left local gradients in the buckets
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
         if broadcast_init and self.world > 1:
@@ -238,6 +240,10 @@ class GradSync(nn.Module):
             for st in self._bstreams[b]:          # every stream that produced a gradient of this bucket
                 self._comm.wait_stream(st)
             with torch.cuda.stream(self._comm):
+                if self.timeline is not None:     # the moment every gradient of the bucket exists on the device
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.timeline.append((b, flat.numel() * 4, ev))
                 if self._use_bf16(flat) and not self._accumulated:
                     wire = self._wire[b]
                     ops.p_cast_into(flat, wire)
@@ -256,8 +262,50 @@ class GradSync(nn.Module):
             flat.div_(self.world)
 
     # ------------------------------------------------------------------ end of a backward pass
+    def _post_verdict(self):
+        dev = self._flat[0].device if self._flat else self._params[0].device
+        k = len(self._late)
+        self.stats["verdicts"] += 1
+        if dev.type == "cuda" and dist.get_backend(self.group) == "nccl":
+            if self._comm is None:
+                from . import streams
+                self._comm = streams.side_stream("comm", getattr(self, "_main", None))
+            self._comm.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._comm):
+                n = torch.empty(2, dtype=torch.int64, device=dev)
+                n[0].fill_(k)                 # fill kernels: no host-to-device copy, no host synchronisation
+                n[1].fill_(-k)
+                dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+                host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+                host.copy_(n, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._verdicts.append((ev, host, n))
+        else:   # gloo / CPU tensors (tests): nothing to overlap with
+            n = torch.tensor([k, -k], dtype=torch.int64, device=dev)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+            if int(n[0]) != -int(n[1]):
+                raise RuntimeError("GradSync: ranks disagree on the parameters that received late gradients")
+
+    def check_collectives(self, block=False):
+        """Read the posted cross-rank agreements that have arrived (block=True: wait for all of them).  Called at the end of
+        every backward pass; raises on every rank when the ranks disagreed on the parameters that received late gradients."""
+        keep = []
+        for ev, host, n in self._verdicts:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if int(host[0]) != -int(host[1]):
+                    self._verdicts = []
+                    raise RuntimeError("GradSync: ranks disagree on the parameters that received late gradients")
+            else:
+                keep.append((ev, host, n))
+        self._verdicts = keep
+
     def _finalize(self):
         self._callback_queued = False
+        if self._verdicts:
+            self.check_collectives()
         if not self._steady:
             self._build_layout()
             return
@@ -275,14 +323,11 @@ class GradSync(nn.Module):
             if dist.is_initialized():   # also a 1-rank group (bench.py --force-dist): the same branch structure as N > 1
                 self._steady_passes += 1
                 if _CHECK_ALWAYS or self._steady_passes <= _CHECK_PASSES:
-                    # the number of late exchanges must be the same on every rank (data-dependent use): agree first,
-                    # raise everywhere instead of hanging in mismatched collectives.  Blocking host read: first passes only.
-                    dev = self._flat[0].device if self._flat else self._params[0].device
-                    n = torch.tensor([len(self._late), -len(self._late)], dtype=torch.int64, device=dev)
-                    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
-                    self.stats["verdicts"] += 1
-                    if int(n[0]) != -int(n[1]):
-                        raise RuntimeError("GradSync: ranks disagree on the parameters that received late gradients")
+                    # the number of late exchanges must be the same on every rank (data-dependent use): the ranks agree on it
+                    # collectively, and every rank raises instead of hanging in mismatched collectives.  The agreement is
+                    # POSTED here and read when it has arrived (round 5; it was a blocking host read in the first passes:
+                    # the device idled at the start of the next step while the host waited for the end of this one)
+                    self._post_verdict()
                 elif self._late:
                     raise RuntimeError(
                         f"GradSync: {len(self._late)} parameter(s) received a gradient for the first time after the bucket "

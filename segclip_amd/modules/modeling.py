@@ -308,6 +308,21 @@ class SegCLIP(SegCLIPPreTrainedModel):
                                                return_hidden=return_hidden, vis_model=vis_model)
         return sequence_output, visual_output
 
+    # modules/modeling.py:322-336: mean-pooling variants of the similarity inputs.  Dead API in the reference's training path
+    # (its forward uses _loose_similarity on the pooled CLS / EOT features); carried for callers that import them.  Plain
+    # tensor arithmetic on (B, L, D) / (B, G, D) inputs, any device.
+    def _mean_pooling_for_similarity_sequence(self, sequence_output, attention_mask):
+        keep = attention_mask.to(dtype=torch.float).unsqueeze(-1).clone()
+        keep[:, 0, :] = 0.                                       # the start-of-text token does not take part
+        return (sequence_output * keep).sum(dim=1) / keep.sum(dim=1, dtype=torch.float)
+
+    def _mean_pooling_for_similarity_visual(self, visual_output):
+        return visual_output.mean(dim=1)
+
+    def _mean_pooling_for_similarity(self, sequence_output, visual_output, attention_mask):
+        return (self._mean_pooling_for_similarity_sequence(sequence_output, attention_mask),
+                self._mean_pooling_for_similarity_visual(visual_output))
+
     def _loose_similarity(self, sequence_output, visual_output, logit_scale=None):
         """modules/modeling.py:338-362: L2-normalise, clamp(exp(logit_scale), 100), all-gather both
         embedding matrices over RCCL in ONE fused message (training), two logits GEMMs (exact fp32)."""

@@ -62,18 +62,42 @@ class PreTrainedModel(nn.Module):
 
     @classmethod
     def init_preweight(cls, model, state_dict, prefix=None, task_config=None, print_logger=None):
-        """modules/util_module.py:90-147: name-based load, tolerant of missing / unexpected keys."""
+        """modules/util_module.py:90-147: name-based load that NEVER raises on the checkpoint's contents.  Missing and
+        unexpected keys are tolerated, and so are shape mismatches: the reference calls Module._load_from_state_dict per
+        module with its own error list, logs "Weights from pretrained model cause errors ..." and continues - that is how its
+        "reset ViT but keep Text Encoder" branch (modules/modeling.py:41-43) loads a ViT-B/32 archive into a ViT-B/16
+        model: the mismatching tensors keep their freshly initialised values, everything else is taken over.
+        (nn.Module.load_state_dict(strict=False) raises on a size mismatch, so it is not used here.)"""
         if prefix is not None:
             state_dict = {prefix + k: v for k, v in state_dict.items()}
-        res = model.load_state_dict(state_dict, strict=False)
+        own = model.state_dict()                      # name -> tensor sharing storage with the parameters / buffers
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own]
+        errors = []
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k not in own:
+                    continue
+                dst = own[k]
+                if not torch.is_tensor(v):
+                    errors.append('While copying the parameter named "{}", expected torch.Tensor but received {}'.format(k, type(v)))
+                elif tuple(v.shape) != tuple(dst.shape):
+                    errors.append("size mismatch for {}: copying a param with shape {} from checkpoint, the shape in current "
+                                  "model is {}.".format(k, tuple(v.shape), tuple(dst.shape)))
+                else:
+                    dst.copy_(v)
         log = print_logger or logger
         if prefix is None and (task_config is None or getattr(task_config, "local_rank", 0) == 0):
-            if res.missing_keys:
+            if missing:
                 log.warning("Weights of {} not initialized from pretrained model: {}".format(
-                    model.__class__.__name__, "\n   " + "\n   ".join(res.missing_keys)))
-            if res.unexpected_keys:
+                    model.__class__.__name__, "\n   " + "\n   ".join(missing)))
+            if unexpected:
                 log.warning("Weights from pretrained model not used in {}: {}".format(
-                    model.__class__.__name__, "\n   " + "\n   ".join(res.unexpected_keys)))
+                    model.__class__.__name__, "\n   " + "\n   ".join(unexpected)))
+            if errors:
+                log.error("Weights from pretrained model cause errors in {}: {}".format(
+                    model.__class__.__name__, "\n   " + "\n   ".join(errors)))
+        model.last_load_report = {"missing_keys": missing, "unexpected_keys": unexpected, "error_msgs": errors}
         return model
 
     @property

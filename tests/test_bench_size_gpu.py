@@ -219,6 +219,57 @@ def test_b256_full_loss_bf16_against_exact_f32_mode():
         assert lo <= ratios[n] <= hi and cos[n] >= cmin, (n, ratios[n], cos[n])
 
 
+@pytest.mark.parametrize("flags", [{}, FULL_FLAGS], ids=["contrastive", "full_loss"])
+def test_b256_exact_f32_against_cpu_oracle(flags):
+    """The benchmarked SIZE against the oracle itself (the B = 256 tests above compare the HIP bf16 mode
+    with the HIP f32 mode - a self-comparison).  HIP exact-f32 mode, "t18" cross-attention (what bench.py times), ViT-B/16,
+    B = 256, contrastive-only (BASELINE configs[1]) and full loss (configs[3]) against oracle.segclip_forward on the same
+    seeded inputs under torch.no_grad() (forward only: ~1 min of CPU): loss and every logit to 1e-3, the integer maps
+    (8-way hard assignment of all 256 x 196 patches, EOT index, MAE shuffle) array-equal."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["vitb16"]
+    B, seed = 256, 3
+    segclip_amd.set_compute_dtype(torch.float32)
+    segclip_amd.set_cross_mode("t18")
+    try:
+        model, _ = synth.build_model(spec, flags, device=DEV)
+        batch = synth.synthetic_batch(spec, B, seed=seed, device=DEV, with_seg=bool(flags))
+        noise = synth.synthetic_noise(spec, B, seed=seed, device=DEV)
+        items = noise_items(noise, flags) if flags else [("gumbel", noise["gumbel_main"])]
+        with torch.no_grad(), segclip_amd.noise_injection(items):
+            loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"],
+                         image_seg=batch.get("image_seg"))
+        torch.cuda.synchronize()
+        got = dict(loss=float(loss), t2v=model.last_logits[0].float().cpu(), v2t=model.last_logits[1].float().cpu(),
+                   hard_idx=model.last_mid_states["hard_idx"].cpu().long())
+        if getattr(model, "last_mae", None) is not None:
+            got["ids_restore"] = model.last_mae[1].cpu().long()
+            got["mae_hard_idx"] = model.last_mae[2]["hard_idx"].cpu().long()
+        del model, loss
+        torch.cuda.empty_cache()
+    finally:
+        segclip_amd.set_compute_dtype(torch.float32)
+        segclip_amd.set_cross_mode("t18")
+    P = oracle_params(spec, model_param_shapes(spec, flags), requires_grad=False)
+    with torch.no_grad():
+        lo, aux = so.segclip_forward(synth.synthetic_batch(spec, B, seed=seed, with_seg=bool(flags)), P, spec,
+                                     synth.synthetic_noise(spec, B, seed=seed), flags, cross_mode="t18")
+    dl = abs(got["loss"] - float(lo))
+    d1 = float((got["t2v"] - aux["t2v"]).abs().max())
+    d2 = float((got["v2t"] - aux["v2t"]).abs().max())
+    agree = float((got["hard_idx"] == aux["hard_idx"]).float().mean())
+    print(f"\n[B=256 f32 vs oracle, {'full loss' if flags else 'contrastive'}] loss {got['loss']:.6f} vs {float(lo):.6f} (d {dl:.2e}); "
+          f"max |d t2v| {d1:.2e}, |d v2t| {d2:.2e}; hard_idx agreement {agree:.6f}")
+    assert dl <= 1e-3, dl
+    assert d1 <= 1e-3 and d2 <= 1e-3, (d1, d2)
+    assert torch.equal(got["hard_idx"], aux["hard_idx"])
+    if flags:
+        assert torch.equal(got["ids_restore"], aux["ids_restore"].long())
+        if got.get("mae_hard_idx") is not None:
+            assert torch.equal(got["mae_hard_idx"], aux["mae_hard_idx"])
+
+
 def test_b4_bf16_grad_norms_against_reference_golden():
     g = load_golden("vitb16_b4_t18.npz")
     b = _run("vitb16", int(g["B"]), int(g["seed"]), torch.bfloat16, FULL_FLAGS, "t18")

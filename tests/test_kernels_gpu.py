@@ -283,6 +283,7 @@ def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
 def test_self_attention_fp8_forward(B, T, H, hd, causal):
     """e4m3 MFMA forward (BASELINE configs[4]) against the fp32 reference, and against the bf16 kernel on the same
     inputs: per-token Q/K scales keep the logits to ~2 e4m3 ulps, P is quantised to 8 bits -> looser than bf16."""
+    from segclip_amd import _lib
     D = H * hd
     qkv = rnd(B * T, 3 * D, dtype=BF, seed=71)
     s3 = (T * 3 * D, 3 * D)
@@ -291,7 +292,11 @@ def test_self_attention_fp8_forward(B, T, H, hd, causal):
         o = torch.empty(B * T, D, dtype=BF, device=DEV)
         d = ops._attn_desc(qkv, qkv, qkv, o, B, H, T, T, hd, s3, s3, s3, (T * D, D), 1 / math.sqrt(hd), causal, 0, D, 2 * D,
                            fp8=fp8)
-        stats = ops.p_attn_fwd(d, qkv)
+        try:
+            stats = ops.p_attn_fwd(d, qkv)
+        except _lib.Unsupported as e:      # round 5: the e4m3 forward lives in -DSEGCLIP_EXPERIMENTS builds only
+            assert fp8 and "default build" in str(e)
+            pytest.skip("e4m3 attention forward is not in the default build")
         outs[fp8] = (o.float().view(B, T, D), stats.clone())
     qr = qkv.float().view(B, T, 3, D)
     ref = _attn_ref(qr[:, :, 0], qr[:, :, 1], qr[:, :, 2], H, causal)

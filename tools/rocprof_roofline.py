@@ -85,28 +85,41 @@ def per_class(table, n_passes):
     return res
 
 
-def class_union_ms(db, n_passes):
-    """{class: ms per step during which AT LEAST ONE kernel of the class is running} - the union of the class's kernel
-    intervals over all streams.  With the two towers on concurrent streams two GEMMs share the chip and each one's duration
-    stretches: the sum of durations double-counts the machine, the union is the time the device spends on the class."""
+def _merge(iv):
+    """merged (start, end) list of a start-sorted interval list"""
+    out = []
+    cur_s, cur_e = iv[0]
+    for s_, e_ in iv[1:]:
+        if s_ > cur_e:
+            out.append((cur_s, cur_e))
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    out.append((cur_s, cur_e))
+    return out
+
+
+def class_intervals(db):
+    """{class: merged [(start_ns, end_ns)] of its kernel intervals over all streams}, plus "__all__" (any kernel) - what the
+    union figures are computed from (kept as profiles/rNN_bench_intervals.json so that they can be recomputed)."""
     c = sqlite3.connect(db)
     rows = list(c.execute("select start, end, name from kernels order by start"))
     c.close()
     by = {}
     for s_, e_, name in rows:
-        by.setdefault(classify(name), []).append((s_, e_))
-    out = {}
-    for cls, iv in by.items():
-        cur_s, cur_e, tot = iv[0][0], iv[0][1], 0
-        for s_, e_ in iv[1:]:
-            if s_ > cur_e:
-                tot += cur_e - cur_s
-                cur_s, cur_e = s_, e_
-            else:
-                cur_e = max(cur_e, e_)
-        tot += cur_e - cur_s
-        out[cls] = round(tot / 1e6 / n_passes, 3)
-    return out
+        cls = classify(name)
+        by.setdefault(cls, []).append((s_, e_))
+        if cls != "startup_probe":
+            by.setdefault("__all__", []).append((s_, e_))
+    return {cls: _merge(iv) for cls, iv in by.items()}
+
+
+def class_union_ms(db, n_passes, merged=None):
+    """{class: ms per step during which AT LEAST ONE kernel of the class is running} - the union of the class's kernel
+    intervals over all streams.  With the two towers on concurrent streams two GEMMs share the chip and each one's duration
+    stretches: the sum of durations double-counts the machine, the union is the time the device spends on the class."""
+    merged = merged if merged is not None else class_intervals(db)
+    return {cls: round(sum(e_ - s_ for s_, e_ in iv) / 1e6 / n_passes, 3) for cls, iv in merged.items()}
 
 
 def format_table(table, n_passes, header="", top=60):
@@ -144,9 +157,21 @@ def measure(child_argv, n_passes, pmc_argv=None, keep_dir=None, timeout=300):
     table = kernel_table(db)
     res = {"classes": per_class(table, n_passes), "table": table, "child_stdout": out, "traffic": None, "notes": notes}
     try:
-        for cls, ms in class_union_ms(db, n_passes).items():
+        merged = class_intervals(db)
+        for cls, ms in class_union_ms(db, n_passes, merged).items():
             if cls in res["classes"]:
                 res["classes"][cls]["union_ms_per_step"] = ms
+        res["union_all_ms_per_step"] = class_union_ms(db, n_passes, merged).get("__all__")
+        if keep_dir:   # merged intervals per class, microseconds from the first kernel of the trace: the union is recomputable
+            import json
+            t0 = min(iv[0][0] for iv in merged.values())
+            with open(os.path.join(base, "intervals.json"), "w") as f:
+                json.dump({"n_passes": n_passes, "unit": "us from the first kernel of the trace",
+                           "note": "per kernel class: merged [start, end] intervals during which at least one kernel of the class "
+                                   "was running (all streams); union_ms_per_step = sum(end - start) / n_passes / 1000; "
+                                   "__all__ = any kernel except the stream-overlap probe",
+                           "classes": {cls: [[round((s_ - t0) / 1e3, 2), round((e_ - t0) / 1e3, 2)] for s_, e_ in iv]
+                                       for cls, iv in merged.items()}}, f)
     except Exception as e:
         notes.append(f"union busy time not computed: {e}")
     if pmc_argv:
