@@ -63,6 +63,10 @@ def parse():
                          "configs[4], profiles/r03_bench_configs.json); `on` keeps the configs[4] switch reachable")
     ap.add_argument("--resid", default="auto", choices=["auto", "bf16", "fp32"],
                     help="residual stream between the blocks of a tower in bf16 mode (config.bf16_resid); auto = the package default")
+    ap.add_argument("--text-trim", action="store_true",
+                    help="config.text_trim for the TIMED region (opt-in, off by default: the headline times the reference's full "
+                         "77-token context): the causal text tower on the positions up to the batch's last EOT only - identical loss "
+                         "and gradients (tests/test_model_gpu.py); the default run reports it as the secondary field `text_trim`")
     ap.add_argument("--text-after-blocks", type=int, default=-1, help="config.text_after_blocks override (launch order of the towers)")
     ap.add_argument("--wire", default="auto", choices=["auto", "bf16", "fp32"], help="gradient all-reduce wire format (auto = fp32, what the reference DDP exchanges; bf16 is an opt-in)")
     ap.add_argument("--rccl-channels", type=int, default=0,
@@ -201,6 +205,8 @@ def child_argv(a, steps, warmup):
             "--no-parity-leg"]
     if a.full_loss:
         argv.append("--full-loss")
+    if a.text_trim:
+        argv.append("--text-trim")
     return argv
 
 
@@ -376,6 +382,8 @@ def main():
         segclip_amd.config.reduce_side = True
     if a.text_after_blocks >= 0:
         segclip_amd.config.text_after_blocks = a.text_after_blocks
+    if a.text_trim:
+        segclip_amd.config.text_trim = True
     if os.environ.get("SEGCLIP_OVERLAP_TOWERS", "1") == "0":   # experiment: both towers on one stream
         segclip_amd.config.overlap_towers = False
     if os.environ.get("SEGCLIP_OVERLAP_WGRAD", "0") == "1":   # experiment switch: weight gradients on a second stream
@@ -498,6 +506,34 @@ def main():
             except Exception as e:           # never lose the headline line over a secondary field
                 gb2048 = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
 
+    text_trim = None
+    if not a.no_parity_leg and a.dtype == "bf16" and a.spec == "vitb16" and not a.text_trim:
+        # opt-in switch, reported beside the headline (never part of it): dead positions of the causal text tower skipped
+        segclip_amd.config.text_trim = True
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            dtt = (time.perf_counter() - t1) / 10
+            keep = model.clip._trim_len(batch["input_ids"].view(-1, batch["input_ids"].shape[-1]))
+            text_trim = {"pairs_per_s": round(a.batch * world / dtt, 1), "ms_per_step": round(dtt * 1e3, 3), "steps": 10,
+                         "text_positions": f"{keep} of {spec['context_length']}",
+                         "note": "config.text_trim (opt-in, NOT the headline): the causal text tower runs on the positions up to the "
+                                 "batch's last EOT; loss and every gradient equal the full pass (tests/test_model_gpu.py::"
+                                 "test_text_trim_gives_the_same_loss_and_gradients); fewer contraction flops are executed"}
+        finally:
+            segclip_amd.config.text_trim = False
+        step()
+        torch.cuda.synchronize()
+
     roofline = None
     if not a.no_roofline and a.dtype == "bf16":
         # EVERY rank runs the op-count pass (one more step: its collectives must be matched on all ranks - ADVICE r3: with
@@ -535,8 +571,11 @@ def main():
                                             f", backend {a.backend}, RCCL channels {a.rccl_channels or 'default'}"),
                           "residual_stream": ("bf16 between the blocks of a tower, fp32 at the tower boundaries"
                                               if (a.dtype == "bf16" and segclip_amd.config.bf16_resid) else "fp32"),
-                          "cross_mode": segclip_amd.config.cross_mode, "loss": round(loss_val, 5)},
-               "parity_mode": parity_mode, "bf16_vs_f32": bf16_vs_f32, "global_batch_2048_single_gpu": gb2048,
+                          "cross_mode": segclip_amd.config.cross_mode,
+                          "text_positions": ("trimmed to the batch's last EOT (--text-trim)" if a.text_trim else
+                                             f"all {spec['context_length']} (full context, as the reference computes it)"),
+                          "loss": round(loss_val, 5)},
+               "parity_mode": parity_mode, "bf16_vs_f32": bf16_vs_f32, "global_batch_2048_single_gpu": gb2048, "text_trim": text_trim,
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if multi:

@@ -48,6 +48,14 @@ reduce_side   : inside ResStackFn's backward the blocks' trailing reductions (sp
                 41.9 ms per step - with two more active streams the runtime maps the text tower's stream onto the main
                 stream's hardware queue and the towers run one after the other (the effect DESIGN.md 6 "hardware queues"
                 describes)
+text_trim     : training fast path of the text tower (CLIP.encode_text_eot): run the causal tower on the first L tokens only,
+                L = the batch's largest EOT position + 1.  The tower is causal and only the EOT row reaches the loss, so the
+                positions behind a caption's EOT influence neither the loss nor any gradient (their rows of every weight
+                gradient are sums of exact zeros): outputs and gradients are those of the full 77-token pass (fp32 summation
+                order of the weight gradients aside).  With the synthetic captions of SURVEY 8(d) (5-29 body tokens) L = 31 of
+                77.  OFF by default: bench.py times the reference's full context; the switch exists for real caption data
+                (the published recipe itself trains with max_words 32).  L is read with one host synchronisation whenever the
+                id tensor changes (cached by storage / version); `text_trim_hint` (int) avoids it for callers that know it
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -62,7 +70,7 @@ import torch
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
-                 text_after_blocks=4,
+                 text_after_blocks=4, text_trim=False, text_trim_hint=None,
                  wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP_DIST", "12")))
 _tls = threading.local()
 

@@ -106,8 +106,25 @@ class CLIP(CLIP_Module):
         return ops.linear(h, self.text_projection, None, out_dtype=torch.float32, act_dtype=config.compute_dtype,
                           w_kn=True).squeeze(1)
 
+    def _trim_len(self, text):
+        """config.text_trim: number of leading token positions that can reach the loss = largest EOT position + 1."""
+        hint = config.text_trim_hint
+        if hint is not None:
+            return max(1, min(int(hint), text.shape[1]))
+        key = (text.data_ptr(), text._version, tuple(text.shape))
+        c = getattr(self, "_trim_cache", None)
+        if c is None or c[0] != key:
+            c = (key, int(text.argmax(dim=-1).max()) + 1)      # one host synchronisation per new id tensor
+            self._trim_cache = c
+        return max(1, min(c[1], text.shape[1]))
+
     def encode_text_eot(self, text):
-        """Training fast path: only the pooled (EOT) feature."""
+        """Training fast path: only the pooled (EOT) feature.  config.text_trim: the causal tower runs on the positions up to
+        the batch's last EOT only (the rest cannot reach the EOT rows; see config.py)."""
+        if config.text_trim:
+            keep = self._trim_len(text)
+            if keep < text.shape[1]:
+                text = text[:, :keep].contiguous()
         return self._project_eot(self._text_trunk(text), text.argmax(dim=-1))
 
     def forward(self, image, text):

@@ -279,3 +279,47 @@ def test_eval_vitb16_448_sliding_window_size_vs_oracle():
     bfeat, bsoft, bidx = outs[torch.bfloat16]
     assert float((bfeat - of).abs().max()) <= 6e-2
     assert float((bidx == idx).float().mean()) >= 0.97
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_text_trim_gives_the_same_loss_and_gradients(dtype):
+    """config.text_trim (opt-in): the causal text tower on the positions up to the batch's last EOT only.  The positions
+    behind a caption's EOT reach neither the loss nor any gradient, so loss, logits and EVERY parameter gradient equal those
+    of the full 77-token pass: the fp32 mode to fp32 summation-order noise (the weight gradients sum over fewer, all-zero
+    rows), the bf16 mode likewise (every token row is computed by the same instructions either way)."""
+    spec = synth.SPECS["vitb16"]
+    B, seed = 6, 17
+    outs = []
+    for trim in (False, True):
+        segclip_amd.set_compute_dtype(dtype)
+        segclip_amd.config.text_trim = trim
+        try:
+            model, _ = synth.build_model(spec, {}, device=DEV)
+            batch = synth.synthetic_batch(spec, B, seed=seed, device=DEV, with_seg=False)
+            noise = synth.synthetic_noise(spec, B, seed=seed, device=DEV)
+            with segclip_amd.noise_injection([("gumbel", noise["gumbel_main"])]):
+                loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"])
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((float(loss), model.last_logits[0].float().clone(),
+                         {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}))
+            keep = model.clip._trim_len(batch["input_ids"].view(-1, batch["input_ids"].shape[-1])) if trim else None
+            del model, loss
+            torch.cuda.empty_cache()
+        finally:
+            segclip_amd.set_compute_dtype(torch.float32)
+            segclip_amd.config.text_trim = False
+    (l0, t0, g0), (l1, t1, g1) = outs
+    assert keep is not None and 7 <= keep <= 31, keep                 # SURVEY 8(d) captions: 5-29 body tokens + SOT + EOT
+    assert abs(l0 - l1) <= 1e-6 and float((t0 - t1).abs().max()) <= 1e-5, (l0, l1)
+    assert set(g0) == set(g1)
+    worst = 0.0
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        err = float((g0[n] - g1[n]).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 2e-5 * scale + 1e-9, (n, err, scale)
+    pos = g1["clip.positional_embedding"]
+    assert float(pos[keep:].abs().max()) == 0.0 and float(g0["clip.positional_embedding"][keep:].abs().max()) == 0.0
+    print(f"\n[text_trim {dtype}] {keep} of {spec['context_length']} positions; loss {l1:.6f} vs {l0:.6f}; worst gradient "
+          f"difference {worst:.2e} of the tensor's max")
