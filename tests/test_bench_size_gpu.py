@@ -270,14 +270,16 @@ def test_b256_exact_f32_against_cpu_oracle(flags):
     # The 8-way argmax of 50176 patches is an integer function of fp32 sums taken in different orders (the GPU's MFMA fmaf chain,
     # the CPU's blocked GEMM): it is bit-exact at B <= 5 (test_model_gpu.py) and may flip on an exact NEAR-TIE at this size
     # (measured round 5: 1 patch of 50176).  Every differing patch must BE such a tie - the oracle's own soft assignment of the
-    # two candidates equal to 1e-4 relative - and there may be at most a handful; anything else is a real error.
+    # two candidates' noisy logits equal to 2e-4 - and there may be at most a handful; anything else is a real error.
     assert mism.shape[0] <= 5, mism.shape[0]
-    soft = aux["soft"]                                   # (B, 8, 196): softmax over the centers of (logits + gumbel) / tau
+    # the decision is argmax_c (logit_c + gumbel_c); soft = softmax_c(logit_c) (no noise), so logit differences = log-soft differences
+    soft, gmb = aux["soft"].double(), synth.synthetic_noise(spec, B, seed=seed)["gumbel_main"].double()
     for b_, t_ in mism.tolist():
         co, ch = int(aux["hard_idx"][b_, t_]), int(got["hard_idx"][b_, t_])
-        so_, sh_ = float(soft[b_, co, t_]), float(soft[b_, ch, t_])
-        print(f"    near-tie at sample {b_} patch {t_}: oracle center {co} ({so_:.7f}) vs HIP center {ch} ({sh_:.7f})")
-        assert abs(so_ - sh_) <= 1e-4 * so_, (b_, t_, so_, sh_)
+        yo = float(soft[b_, co, t_].log() + gmb[b_, co, t_])
+        yh = float(soft[b_, ch, t_].log() + gmb[b_, ch, t_])
+        print(f"    near-tie at sample {b_} patch {t_}: oracle center {co} (logit + noise {yo:.7f}) vs HIP center {ch} ({yh:.7f})")
+        assert abs(yo - yh) <= 2e-4 * max(1.0, abs(yo)), (b_, t_, yo, yh)      # measured: 4.9e-5 (fp32 noise after 10 blocks)
     if mism.shape[0] == 0:
         assert d1 <= 1e-3 and d2 <= 1e-3, (d1, d2)
     else:   # in "t18" mode a flipped patch reaches other samples' features through the cross-sample key mixing (finding 0.4)

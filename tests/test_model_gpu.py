@@ -311,14 +311,15 @@ def test_text_trim_gives_the_same_loss_and_gradients(dtype):
             segclip_amd.config.text_trim = False
     (l0, t0, g0), (l1, t1, g1) = outs
     assert keep is not None and 7 <= keep <= 31, keep                 # SURVEY 8(d) captions: 5-29 body tokens + SOT + EOT
-    assert abs(l0 - l1) <= 1e-6 and float((t0 - t1).abs().max()) <= 1e-5, (l0, l1)
+    assert abs(l0 - l1) <= (1e-6 if dtype == torch.float32 else 1e-4) and float((t0 - t1).abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-3), (l0, l1)
     assert set(g0) == set(g1)
     worst = 0.0
     for n in g0:
         scale = float(g0[n].abs().max())
         err = float((g0[n] - g1[n]).abs().max())
         worst = max(worst, err / max(scale, 1e-12))
-        assert err <= 2e-5 * scale + 1e-9, (n, err, scale)
+        # bf16 mode: the bias / positional sums are taken over another number of (partly zero) bf16-rounded rows in another order
+        assert err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale + 1e-9, (n, err, scale)
     pos = g1["clip.positional_embedding"]
     assert float(pos[keep:].abs().max()) == 0.0 and float(g0["clip.positional_embedding"][keep:].abs().max()) == 0.0
     print(f"\n[text_trim {dtype}] {keep} of {spec['context_length']} positions; loss {l1:.6f} vs {l0:.6f}; worst gradient "

@@ -9,21 +9,24 @@ export TMPDIR=/tmp
 F='^RCCL\|^HIP\|^ROCm\|Hostname\|Librccl\|amdgpu.ids\|socket.cpp\|ProcessGroupNCCL'
 SEGCLIP_BENCH_PROFILE_DIR=$OUT/rl timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
 cp $OUT/rl/kernel_stats.txt $OUT/kernel_stats.txt
+cp $OUT/rl/intervals.json $OUT/bench_intervals.json 2>/dev/null
 python tools/stream_gaps.py $(ls $OUT/rl/trace/*.db $OUT/rl/trace/*/*.db 2>/dev/null | head -1) 120 > $OUT/stream_gaps.txt 2>&1
 rm -rf $OUT/rl/trace $OUT/rl/pmc_*
 b() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "$name: $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$name.json) $(grep -o '"value": [0-9.]*' $OUT/bench_$name.json | head -1)"; }
-b gb2048 --no-cpu-baseline --no-traffic --global-batch 2048 --steps 5 --warmup 2
-b full_loss --no-cpu-baseline --no-traffic --full-loss
-b resid_bf16 --no-cpu-baseline --no-roofline --resid bf16
-b dist --no-cpu-baseline --no-roofline --force-dist
-b dist_bf16wire --no-cpu-baseline --no-roofline --force-dist --wire bf16
-b vitl14 --no-cpu-baseline --no-traffic --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
-b vitl14_fp8 --no-cpu-baseline --no-roofline --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 on
-for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --batch $bsz; done
+b gb2048 --no-cpu-baseline --no-traffic --no-parity-leg --global-batch 2048 --steps 5 --warmup 2
+b full_loss --no-cpu-baseline --no-traffic --no-parity-leg --full-loss
+b resid_bf16 --no-cpu-baseline --no-roofline --no-parity-leg --resid bf16
+b plain_ref --no-cpu-baseline --no-roofline --no-parity-leg
+b dist --no-cpu-baseline --no-roofline --no-parity-leg --force-dist
+b dist_bf16wire --no-cpu-baseline --no-roofline --no-parity-leg --force-dist --wire bf16
+b plain_ref2 --no-cpu-baseline --no-roofline --no-parity-leg
+b vitl14 --no-cpu-baseline --no-traffic --no-parity-leg --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
+b text_trim --no-cpu-baseline --no-roofline --no-parity-leg --text-trim
+for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --no-parity-leg --batch $bsz; done
 # same-box A/B of the grouped weight gradients (config.wgrad_group_blocks): one launch per gradient vs the default, twice
 for rep in a b; do
-  SEGCLIP_WGRAD_GROUP=1 b wgrad_single_$rep --no-cpu-baseline --no-roofline --steps 30 --warmup 8
-  b wgrad_grouped_$rep --no-cpu-baseline --no-roofline --steps 30 --warmup 8
+  SEGCLIP_ATTN_FWD_PF=0 b attn_fwd_old_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
+  b attn_fwd_pf_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
 done
 timeout 300 python tools/debug/center_stage_profile.py 2>&1 | grep -v "$F" | grep -v "Warning\|warn" > $OUT/center_stage.txt
 timeout 300 python tools/bench_hbm.py 2>&1 | grep -v "$F" > $OUT/hbm_kernels.txt
@@ -39,5 +42,7 @@ for spec in "50176 768 3072 nt" "50176 3072 768 dgrad" "50176 2304 768 wgrad"; d
   timeout 600 bash tools/pmc_gemm.sh $1 $2 $3 $4 $OUT/pmc_gemm_$4 > $OUT/pmc_gemm_$4.txt 2>&1
 done
 timeout 600 bash tools/pmc_attn.sh $OUT/pmc_attn 256 196 12 0 > $OUT/pmc_attn.txt 2>&1
+timeout 300 python tools/bucket_timeline.py $OUT/bucket_timeline.txt > $OUT/bucket_timeline.log 2>&1
+timeout 600 python tools/accuracy_b256.py > $OUT/accuracy_b256.txt 2>&1
 rm -rf $OUT/pmc_gemm_*/*/ $OUT/pmc_attn/*/ 2>/dev/null
 head -30 $OUT/kernel_stats.txt | cut -c1-150; cat $OUT/stream_gaps.txt | head -5; tail -c 600 $OUT/bench_line.json
