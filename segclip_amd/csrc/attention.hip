@@ -615,6 +615,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 
 #include "attention_sp.inc"
 #include "attention_pf.inc"
+#include "attention_spl.inc"
 #include "attention_stream.inc"
 // e4m3 forward (BASELINE configs[4] as first read): forward-only, non-scaled e4m3 MFMA = the bf16 rate, measured SLOWER than the
 // bf16 kernel in every round (1350 vs 1395 pairs/s at B = 128, profiles/r04_bench_configs.json).  Round 5: out of the default
@@ -896,6 +897,23 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
       if (grid_env > 0) per_cu = grid_env;
       int64_t grid = grid_env == 0 ? a.nitems : (int64_t)ncu * per_cu;
       if (grid > a.nitems) grid = a.nitems;
+      // vision tower (no mask, 5-7 tiles): the variant whose memory traffic is issued by a loader wave (attention_spl.inc);
+      // SEGCLIP_ATTN_BWD_SPL=0 keeps attention_sp.inc
+      static const int use_spl = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_SPL"); return e ? atoi(e) : 1; }();
+      if (use_spl && !masked && tiles >= 5 && tiles <= 7 && bwd_spl_lds_bytes((int)d->Tq) <= 160 * 1024) {
+        static bool spl_attr_set[64] = {};
+        if (!spl_attr_set[dev]) {
+          hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_spl_bf16_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          SEGCLIP_REQUIRE(e3 == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e3));
+          spl_attr_set[dev] = true;
+        }
+        int64_t g2 = grid_env == 0 ? a.nitems : (int64_t)ncu * (grid_env > 0 ? grid_env : 1);
+        if (g2 > a.nitems) g2 = a.nitems;
+        hipLaunchKernelGGL(attn_bwd_spl_bf16_kernel, dim3((unsigned)g2), dim3((tiles + 1) * 64), bwd_spl_lds_bytes((int)d->Tq), stream, a);
+        SEGCLIP_CHECK_LAUNCH("attn_bwd_spl_bf16");
+        return 0;
+      }
       if (masked)
         hipLaunchKernelGGL(attn_bwd_sp_bf16_kernel<true>, dim3((unsigned)grid), dim3(tiles * 64), lds_sp, stream, a);
       else
