@@ -35,6 +35,10 @@ for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base o
                 ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("plain_ref", "default configuration right before the `dist` / `dist_bf16wire` lines (same box)"),
                 ("plain_ref2", "the same, after the dist lines"),
                 ("b64", "--batch 64"), ("b128", "--batch 128"), ("b512", "--batch 512"),
+                ("text_trim", "--text-trim: config.text_trim in the timed region (opt-in; causal text tower up to the batch's last EOT)"),
+                ("attn_fwd_old_a", "SEGCLIP_ATTN_FWD_PF=0 (one workgroup per item attention forward), same box, --steps 30"),
+                ("attn_fwd_pf_a", "default (persistent attention forward), same box, --steps 30"),
+                ("attn_fwd_old_b", "SEGCLIP_ATTN_FWD_PF=0, second pass"), ("attn_fwd_pf_b", "default, second pass"),
                 ("wgrad_single_a", "SEGCLIP_WGRAD_GROUP=1 (one launch per weight gradient), same box, --steps 30"),
                 ("wgrad_grouped_a", "default (grouped weight gradients), same box, --steps 30"),
                 ("wgrad_single_b", "SEGCLIP_WGRAD_GROUP=1, second pass"), ("wgrad_grouped_b", "default, second pass")):
@@ -90,4 +94,11 @@ if os.path.exists(R + "eager_ab.json"):
     e["segclip_amd_same_run"] = {"pairs_per_s": line["value"], "ms_per_step": line["ms_per_step"]}
     e["speedup_vs_eager"] = round(line["value"] / e["pairs_per_s"], 2)
     json.dump(e, open(P + "eager_ab.json", "w"), indent=1)
+import shutil
+for a, b in (("bench_intervals.json", "bench_intervals.json"), ("bucket_timeline.txt", "bucket_timeline.txt")):
+    if os.path.exists(R + a):
+        shutil.copy(R + a, P + b)
+if os.path.exists(R + "accuracy_b256.txt"):
+    body = "".join(l for l in open(R + "accuracy_b256.txt") if not re.match(r"^(RCCL|HIP|ROCm|Hostname|Librccl)|amdgpu.ids", l))
+    open(P + "accuracy_b256.txt", "w").write(body)
 print("wrote", P + "*")
