@@ -48,6 +48,9 @@ constexpr int AO_OFF = 65536;                 // uint8 saved-derivative patches 
 constexpr int SI1_OFF = 98304;                // side-in of the second half (PQ_DACT8: uint8, J * 16 KiB)
 constexpr int SI0_OFF = EXTRA;                // side-in of the first half, fetched during the K loop
 constexpr int BIAS_OFF = EXTRA;               // bias: wave * 256 B (modes with a bias have no side-in)
+// half-tile tail (128 x 256 workgroups, see pq_main): a 3-slot ring of {A0, B0, B1} = 3 x 48 KiB, the bias behind it
+constexpr int HSLOT = 3 * UNIT;
+constexpr int BIAS_OFF_H = 3 * HSLOT;         // 144 KiB
 
 enum { PQ_PLAIN = 0, PQ_RES = 1, PQ_ACT8 = 2, PQ_DACT8 = 3, PQ_SLAB = 4, PQ_RES32 = 5 };
 
@@ -66,6 +69,9 @@ struct PQArgs {
   int tail_S, tail_r, nfull;
   float* tail_ws; int* tail_cnt;
   int rmod;              // PQ_RES32: > 0 -> residual row = output row % rmod (a table broadcast over the samples)
+  // half-tile tail (every mode but PQ_SLAB): the half_r tiles of the last, partial round of 256 workgroups run as
+  // 2 * half_r workgroups of 128 x 256 (workgroups nfull ..: the upper / lower 128 rows of tile nfull + j / 2)
+  int half_r;
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
@@ -524,10 +530,26 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
       unit = xcd * qf + (bid >> 3);
     }
   }
+  // half-tile tail: workgroups nfull .. are the 128-row halves of the tail tiles; the half sequence (tile-major) is cut into
+  // 8 contiguous chunks, one per XCD, like the full tiles in front of it
+  constexpr bool HALF_OK = MODE != PQ_SLAB;
+  bool half = false;
+  int hsel = 0;
+  if (HALF_OK && !A_KS && g.half_r > 0) {
+    if (bid >= g.nfull) {
+      const int j = bid - g.nfull, n2 = 2 * g.half_r, q8h = n2 >> 3, r8h = n2 & 7;
+      const int hu = (xcd < r8h ? xcd * (q8h + 1) : r8h * (q8h + 1) + (xcd - r8h) * q8h) + (j >> 3);
+      unit = g.nfull + (hu >> 1);
+      hsel = hu & 1;
+      half = true;
+    } else {
+      unit = xcd * (g.nfull >> 3) + (bid >> 3);   // nfull is a multiple of 256
+    }
+  }
   const int ksplit = MODE == PQ_SLAB ? unit / g.ntiles : 0;
   const int tile = MODE == PQ_SLAB ? unit - ksplit * g.ntiles : unit;
   const int tcol = tile % g.nbx, trow = tile / g.nbx;
-  const int64_t m0 = (int64_t)trow * BT, n0 = (int64_t)tcol * BT;
+  const int64_t m0 = (int64_t)trow * BT + hsel * 128, n0 = (int64_t)tcol * BT;
   const int nkt = g.K / BK;
   const int tk0 = tail ? tsplit * nkt / g.tail_S : 0;
   const int64_t kb = MODE == PQ_SLAB ? (int64_t)ksplit * g.kper : (int64_t)tk0 * BK;
@@ -543,7 +565,7 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
   constexpr bool HAS_BIAS = MODE == PQ_PLAIN || MODE == PQ_ACT8;   // bias added in the accumulator layout (PQ_RES: in the row pass)
   const bool has_bias = HAS_BIAS && g.bias != nullptr;
   if (has_bias)   // this wave's 2 x 32 columns: lane l -> column (l>>5)*128 + wc*32 + (l&31)
-    dma4(g.bias + n0 + wc * 32, (uint32_t)(((lane >> 5) * 128 + (lane & 31)) * 4), lds0 + BIAS_OFF + wave * 256);
+    dma4(g.bias + n0 + wc * 32, (uint32_t)(((lane >> 5) * 128 + (lane & 31)) * 4), lds0 + (half ? BIAS_OFF_H : BIAS_OFF) + wave * 256);
   // PQ_DACT8: saved-derivative bytes of one half (2 quadrants x [128 rows][128 B]) = 32 pieces of 1 KiB (8 rows each), 4 per
   // wave; lane l of piece p: row (p&15)*8 + (l>>3), physical chunk l&7 <- logical chunk (l&7) ^ (row&7)
   auto side_half = [&](int I, uint32_t dst) {
@@ -554,7 +576,7 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
       dma16(sb, (uint32_t)(r * g.lds + J * 128 + (((lane & 7) ^ (r & 7)) << 4)), lds0 + dst + p * 1024);
     }
   };
-  if constexpr (MODE == PQ_DACT8) side_half(0, SI0_OFF);
+  if constexpr (MODE == PQ_DACT8) { if (!half) side_half(0, SI0_OFF); }   // half-tile: the 3-slot ring covers SI0_OFF, fetched after the K loop
 
   uint32_t offA[2][2], offB[2][2];
 #pragma unroll
@@ -566,6 +588,114 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
     }
   const uint32_t lds_ring = lds0 + wave * 2048;
   lds_cchar* const sm3 = (lds_cchar*)smem;
+  bf16x8_t fa[2][4], fbx[4], fby[4];
+  using std::integral_constant;
+  typedef integral_constant<int, 0> I0;
+  typedef integral_constant<int, 1> I1;
+  // 8 MFMAs of one C quadrant (A half I, B half J) and one K-tile; srcA = B fragment: the result block is transposed
+  auto quadrant = [&](auto ic, auto jc, auto zc, const bf16x8_t (&fb)[4]) {
+    constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
+    constexpr bool Z = decltype(zc)::value != 0;
+    __builtin_amdgcn_s_setprio(1);
+    mfma_acc<(I * 2 + 0) * 2 + J, Z>(fb[0], fa[0][0]);
+    mfma_acc<(I * 2 + 1) * 2 + J, Z>(fb[0], fa[1][0]);
+#pragma unroll
+    for (int kc = 1; kc < 4; ++kc) {
+      mfma_acc<(I * 2 + 0) * 2 + J, false>(fb[kc], fa[0][kc]);
+      mfma_acc<(I * 2 + 1) * 2 + J, false>(fb[kc], fa[1][kc]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+
+  if (HALF_OK && !A_KS && half) {
+    // ---- half-tile K loop: a 128 x 256 output (A0 only), two phases per K-tile - L1: A0(t), B0(t) fragments, stage A0(t+2);
+    // L2: B1(t) fragments, stage B0(t+2), B1(t+2) - on a 3-slot ring (tile t in slot t % 3), so that a unit travels for two
+    // K-tiles (8 barrier intervals) as in the full-tile schedule.  A unit of tile t-1 is overwritten two intervals after the
+    // lagging wave group consumed it.  VM queue per wave: ... B1(t) | A0(t+1) B0(t+1) B1(t+1) A0(t+2) | -> vmcnt(8) retires B1(t)
+    // at the end of L1(t); ... A0(t+1) B0(t+1) | B1(t+1) A0(t+2) B0(t+2) B1(t+2) -> vmcnt(8) retires both at the end of L2(t).
+    if constexpr (HALF_OK && !A_KS) {
+      lds_cchar* abh[3][4];
+      lds_cchar* bbh[3][4];
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          uint32_t oa = fragbase_direct(wr * 64, x, lane);
+          uint32_t ob = B_KS ? fragbase_ks(wc * 32, lane) : fragbase_direct(wc * 32, x, lane);
+          oa += sl * HSLOT; ob += sl * HSLOT + UNIT;
+          asm volatile("" : "+v"(oa));
+          if ((!B_KS || x < 1)) asm volatile("" : "+v"(ob));
+          abh[sl][x] = sm3 + oa;
+          bbh[sl][x] = sm3 + ob;
+        }
+      typedef integral_constant<int, 2> I2;
+      auto stage_h = [&](int u, int t, int sl) {   // u: 0 = A0, 1 = B0, 2 = B1
+        const uint32_t dst = lds_ring + sl * HSLOT + u * UNIT;
+        if (u == 0) dma16x2(baseA + (int64_t)t * stepA, offA[0][0], offA[0][1], dst);
+        else dma16x2(baseB + (int64_t)t * stepB, offB[u - 1][0], offB[u - 1][1], dst);
+      };
+      auto read_a_h = [&](auto sc) {
+        constexpr int SL = decltype(sc)::value;
+        fa[0][0] = frag_direct_at<0>(abh[SL][0]); fa[0][1] = frag_direct_at<0>(abh[SL][1]);
+        fa[0][2] = frag_direct_at<0>(abh[SL][2]); fa[0][3] = frag_direct_at<0>(abh[SL][3]);
+        fa[1][0] = frag_direct_at<4096>(abh[SL][0]); fa[1][1] = frag_direct_at<4096>(abh[SL][1]);
+        fa[1][2] = frag_direct_at<4096>(abh[SL][2]); fa[1][3] = frag_direct_at<4096>(abh[SL][3]);
+      };
+      auto read_b_h = [&](auto sc, auto uc, bf16x8_t (&fb)[4]) {
+        constexpr int SL = decltype(sc)::value, U = decltype(uc)::value;
+        if constexpr (B_KS) {
+          fb[0] = frag_ks_at<U + 0 * 4096>(bbh[SL][0]); fb[1] = frag_ks_at<U + 1 * 4096>(bbh[SL][0]);
+          fb[2] = frag_ks_at<U + 2 * 4096>(bbh[SL][0]); fb[3] = frag_ks_at<U + 3 * 4096>(bbh[SL][0]);
+        } else {
+          fb[0] = frag_direct_at<U>(bbh[SL][0]); fb[1] = frag_direct_at<U>(bbh[SL][1]);
+          fb[2] = frag_direct_at<U>(bbh[SL][2]); fb[3] = frag_direct_at<U>(bbh[SL][3]);
+        }
+      };
+      stage_h(1, 0, 0);
+      stage_h(0, 0, 0);
+      stage_h(2, 0, 0);
+      if (nk > 1) {
+        stage_h(1, 1, 1);
+        stage_h(0, 1, 1);
+        stage_h(2, 1, 1);
+        wait_vm<8>();    // B0(0), A0(0) have landed
+      } else {
+        wait_vm<2>();
+      }
+      PQ_BAR();
+      if (wr == 1) PQ_BAR();
+      auto ktile_h = [&](auto sc, auto zc, int t) {
+        typedef decltype(sc) SL;
+        typedef integral_constant<int, (SL::value + 2) % 3> NS;
+        typedef decltype(zc) Z;
+        const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+        // ---- phase 1: quadrant (A0, B0)
+        read_a_h(SL{});
+        read_b_h(SL{}, integral_constant<int, 0>{}, fbx);
+        if (n2) { stage_h(0, t + 2, NS::value); wait_vm<8>(); } else if (n1) { wait_vm<6>(); } else { wait_vm<0>(); }   // retires B1(t)
+        PQ_BAR();
+        quadrant(I0{}, I0{}, Z{}, fbx);
+        PQ_BAR();
+        // ---- phase 2: quadrant (A0, B1)
+        read_b_h(SL{}, integral_constant<int, UNIT>{}, fby);
+        if (n2) { stage_h(1, t + 2, NS::value); stage_h(2, t + 2, NS::value); wait_vm<8>(); } else if (n1) { wait_vm<2>(); }   // retires A0(t+1), B0(t+1)
+        PQ_BAR();
+        quadrant(I0{}, I1{}, Z{}, fby);
+        PQ_BAR();
+      };
+      ktile_h(I0{}, I1{}, 0);
+      int t = 1;
+      while (t < nk) {
+        ktile_h(I1{}, I0{}, t);
+        if (++t >= nk) break;
+        ktile_h(I2{}, I0{}, t);
+        if (++t >= nk) break;
+        ktile_h(I0{}, I0{}, t);
+        ++t;
+      }
+    }
+  } else {
   lds_cchar* abase[2][4];
   lds_cchar* bbase[2][4];
 #pragma unroll
@@ -588,10 +718,6 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
     else dma16x2(baseB + (int64_t)t * stepB, offB[u - 2][0], offB[u - 2][1], dst);
   };
 
-  bf16x8_t fa[2][4], fbx[4], fby[4];
-  using std::integral_constant;
-  typedef integral_constant<int, 0> I0;
-  typedef integral_constant<int, 1> I1;
   auto read_a = [&](auto bfc, auto uc) {
     constexpr int BF_ = decltype(bfc)::value, U = decltype(uc)::value;
     if constexpr (A_KS) {
@@ -616,21 +742,6 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
       fb[2] = frag_direct_at<U>(bbase[BF_][2]); fb[3] = frag_direct_at<U>(bbase[BF_][3]);
     }
   };
-  // 8 MFMAs of one C quadrant (A half I, B half J) and one K-tile; srcA = B fragment: the result block is transposed
-  auto quadrant = [&](auto ic, auto jc, auto zc, const bf16x8_t (&fb)[4]) {
-    constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
-    constexpr bool Z = decltype(zc)::value != 0;
-    __builtin_amdgcn_s_setprio(1);
-    mfma_acc<(I * 2 + 0) * 2 + J, Z>(fb[0], fa[0][0]);
-    mfma_acc<(I * 2 + 1) * 2 + J, Z>(fb[0], fa[1][0]);
-#pragma unroll
-    for (int kc = 1; kc < 4; ++kc) {
-      mfma_acc<(I * 2 + 0) * 2 + J, false>(fb[kc], fa[0][kc]);
-      mfma_acc<(I * 2 + 1) * 2 + J, false>(fb[kc], fa[1][kc]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-
   // prologue: K-tile 0 and, of K-tile 1, everything but A1 (issued in R1 of K-tile 0)
   stage(2, 0);
   stage(0, 0);
@@ -686,6 +797,7 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
     ktile(I0{}, I0{}, t + 1, fbx, fby);
   }
   if (t < nk) ktile(I1{}, I0{}, t, fby, fbx);
+  }
   if (wr == 0) PQ_BAR();     // group 0 catches up: every wave is done with the operand ring, the VM queue is empty
 
   if (g.abl & 2) return;
@@ -732,8 +844,9 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
     } while (0)
     PQ_BLOCKS32(0);
     pq_rows_q_f32<0, 0, RES>(g, out, sm3, lane, wave, m0, n0, ra, bias4);
-    if constexpr (RES) pq_res32_issue<1, 0>(g, lane, wave, m0, n0, ra);     // the second half's rows travel under the rest
+    if constexpr (RES) { if (!half) pq_res32_issue<1, 0>(g, lane, wave, m0, n0, ra); }   // the second half's rows travel under the rest
     pq_rows_q_f32<0, 1, RES>(g, out, sm3, lane, wave, m0, n0, rb8, bias4);
+    if (HALF_OK && half) return;                                            // half-tile workgroup: 128 rows only
     if constexpr (RES) pq_res32_issue<1, 1>(g, lane, wave, m0, n0, rb8);
     PQ_BAR_LDS();
     PQ_BLOCKS32(1);
@@ -742,13 +855,16 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
 #undef PQ_BLOCKS32
     return;
   }
-  if constexpr (MODE == PQ_DACT8) side_half(1, SI1_OFF);   // lands under the first half's arithmetic
+  if constexpr (MODE == PQ_DACT8) {
+    if (half) { side_half(0, SI1_OFF); wait_vm<0>(); PQ_BAR(); }   // half-tile: its only side-in, into ring space (exposed once per tail workgroup)
+    else side_half(1, SI1_OFF);                                     // lands under the first half's arithmetic
+  }
   f32x4 bias[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      bias[j][q] = has_bias ? *reinterpret_cast<lds_cf32x4*>(sm3 + BIAS_OFF + wave * 256 + (j * 32 + q * 8 + lk * 4) * 4)
+      bias[j][q] = has_bias ? *reinterpret_cast<lds_cf32x4*>(sm3 + (half ? BIAS_OFF_H : BIAS_OFF) + wave * 256 + (j * 32 + q * 8 + lk * 4) * 4)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
   // MFMA results -> v_accvgpr_read: the last MFMA was issued a barrier ago; 16-pass XDL needs 18 wait states
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
@@ -770,14 +886,15 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
     pq_block<MODE, I, 1, 1>(g, smw, bias[1], li, lk, wr, wc, SI);              \
     PQ_BAR_LDS();                                                              \
     if constexpr (MODE == PQ_RES) {                                            \
-      if (I == 0) pq_res_issue<1>(g, lane, wave, m0, n0, res1);                \
+      if (I == 0 && !half) pq_res_issue<1>(g, lane, wave, m0, n0, res1);       \
       pq_rows_half_res<I>(g, sm3, lane, wave, m0, n0, RESV, bv);               \
     } else {                                                                   \
       pq_rows_half<MODE, I>(g, sm3, lane, wave, m0, n0);                       \
     }                                                                          \
     if constexpr (MODE == PQ_ACT8) pq_rows_aux<I>(g, sm3, lane, wave, m0, n0); \
   } while (0)
-  PQ_HALF(0, SI0_OFF, res0);
+  PQ_HALF(0, (MODE == PQ_DACT8 && half ? SI1_OFF : SI0_OFF), res0);
+  if (HALF_OK && half) return;   // half-tile workgroup: 128 rows only
   // second half: its side-in pieces (4 per wave) are older than the first half's 8 output stores of this wave
   if constexpr (MODE == PQ_DACT8) { if (g.abl & 1) wait_vm<0>(); else wait_vm<8>(); }
   PQ_BAR_LDS();   // the patches are free again (and every wave's side-in pieces have landed)
@@ -863,6 +980,17 @@ static int pq_tail_plan(int64_t ntiles, int64_t nkt, int* r_out) {
   *r_out = r;
   return S;
 }
+// Half-tile tail plan: the r = ntiles % 256 tiles of the last, partial round run as 2 r workgroups of 128 x 256 when those fit
+// one round (r <= 128): 591 tiles (N = 768 at M = 50432) are 2.3 rounds of 256 CUs and take the time of 3; the third round
+// then costs a half-tile's time (about 0.6 of a tile's: 3 of 4 operand units per K-tile, half the MFMAs, half the output).
+// No exchange between workgroups, results bit-identical to the full tiles'.  SEGCLIP_PQ_HALF=0 switches it off (A/B).
+static int pq_half_plan(int64_t ntiles) {
+  static const int env = [] { const char* e = getenv("SEGCLIP_PQ_HALF"); return e ? atoi(e) : 1; }();
+  const int now = env == 2 ? [] { const char* e = getenv("SEGCLIP_PQ_HALF_NOW"); return e ? atoi(e) : 1; }() : env;
+  if (!now || ntiles <= 256) return 0;
+  const int r = (int)(ntiles % 256);
+  return r > 0 && r <= 128 ? r : 0;
+}
 static size_t pq_tail_ws_bytes(int r, int S) { return 4096 + (size_t)r * S * 128 * 512 * sizeof(float); }
 // workspace the tail split of this descriptor wants (0 = none): counters (4 KiB) + partial tiles
 size_t segclip_gemm_bf16_pq_tail_ws_bytes(const segclip_gemm_desc* d) {
@@ -874,10 +1002,15 @@ size_t segclip_gemm_bf16_pq_tail_ws_bytes(const segclip_gemm_desc* d) {
   return S ? pq_tail_ws_bytes(r, S) : 0;
 }
 // fills the tail-split fields of g when the caller's workspace allows it; zeroes the arrival counters on the stream
-static bool pq_tail_setup(PQArgs& g, const segclip_gemm_desc* d, hipStream_t stream, unsigned* nwg) {
+static bool pq_tail_setup(PQArgs& g, const segclip_gemm_desc* d, hipStream_t stream, unsigned* nwg, bool allow_half) {
   int r = 0;
   const int S = pq_tail_plan(g.ntiles, g.K / BK, &r);
   *nwg = (unsigned)g.ntiles;
+  if (!S && allow_half) {
+    const int hr = pq_half_plan(g.ntiles);
+    if (hr > 0) { g.half_r = hr; g.nfull = g.ntiles - hr; *nwg = (unsigned)(g.nfull + 2 * hr); }
+    return true;
+  }
   if (!S || d->ws == nullptr || (size_t)d->ws_bytes < pq_tail_ws_bytes(r, S) || (reinterpret_cast<uintptr_t>(d->ws) & 15) != 0) return true;
   if (hipMemsetAsync(d->ws, 0, 4096, stream) != hipSuccess) return false;
   g.tail_S = S; g.tail_r = r; g.nfull = g.ntiles - r;
@@ -938,7 +1071,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
     g.abl = mode_env == 2 ? segclip_ablation_env("SEGCLIP_PQ_ABL") : 0;
     unsigned nwg = 0;
-    if (!pq_tail_setup(g, d, stream, &nwg)) return false;
+    if (!pq_tail_setup(g, d, stream, &nwg, true)) return false;
     segclip_pq_launch_f(PQ_RES32, dim3(nwg), stream, &g);
     return true;
   }
@@ -976,7 +1109,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));
   g.abl = mode_env == 2 ? segclip_ablation_env("SEGCLIP_PQ_ABL") : 0;
   unsigned nwg = 0;
-  if (!pq_tail_setup(g, d, stream, &nwg)) return false;
+  if (!pq_tail_setup(g, d, stream, &nwg, true)) return false;
   (b_ks ? segclip_pq_launch_k : segclip_pq_launch_f)(mode, dim3(nwg), stream, &g);
   return true;
 }
