@@ -488,6 +488,15 @@ size_t segclip_wgrad_group_ws_bytes(const segclip_wgrad_item* items, int n, int 
 int segclip_wgrad_group(const segclip_wgrad_item* items, int n, int64_t R, int splits, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Half-tile tail of the 256 x 256-tile bf16 GEMM (segclip_gemm with bf16 operands, M and N multiples of 256; the nn.Linear
+ * products of modules/module_seg_vit.py:162-196).  A launch over `ntiles` output tiles whose last round of 256 workgroups is
+ * at most half full (ntiles > 256, 0 < ntiles % 256 <= 128: out_proj / c_proj and the data gradients of in_proj / c_fc at
+ * 256 x 197 token rows are 591 tiles) runs those tail tiles as twice as many 128 x 256 workgroups.  Results are bit-identical
+ * to the full tiles'.  Returns the number of tail tiles run that way (0 = none; SEGCLIP_PQ_HALF=0 disables it).
+ * ------------------------------------------------------------------------------------------ */
+int segclip_gemm_pq_half_tail(int64_t ntiles);
+
 #ifdef __cplusplus
 }
 #endif

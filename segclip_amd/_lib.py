@@ -81,6 +81,7 @@ SIGNATURES = {
     "segclip_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     "segclip_wgrad_group_splits": (C.c_int, [i64, i64]),
     "segclip_wgrad_group_model_us": (C.c_double, [i64, i64, C.c_int]),
+    "segclip_gemm_pq_half_tail": (C.c_int, [i64]),
     "segclip_wgrad_group_ws_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
     "segclip_wgrad_group": (C.c_int, [vp, C.c_int, i64, C.c_int, vp, C.c_size_t, vp]),
     "segclip_layernorm_fwd_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, vp]),

@@ -991,6 +991,8 @@ static int pq_half_plan(int64_t ntiles) {
   const int r = (int)(ntiles % 256);
   return r > 0 && r <= 128 ? r : 0;
 }
+// the number of tail tiles a launch over `ntiles` 256 x 256 tiles runs as half-tiles (0 = none); its grid is ntiles + that
+extern "C" int segclip_gemm_pq_half_tail(int64_t ntiles) { return ntiles > 0 ? pq_half_plan(ntiles) : 0; }
 static size_t pq_tail_ws_bytes(int r, int S) { return 4096 + (size_t)r * S * 128 * 512 * sizeof(float); }
 // workspace the tail split of this descriptor wants (0 = none): counters (4 KiB) + partial tiles
 size_t segclip_gemm_bf16_pq_tail_ws_bytes(const segclip_gemm_desc* d) {

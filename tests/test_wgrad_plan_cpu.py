@@ -53,3 +53,14 @@ def test_group_entry_rejects_what_it_does_not_cover_without_a_gpu():
     assert lib.segclip_wgrad_group(it, 1, 100, 1, None, 0, None) == -2
     assert lib.segclip_wgrad_group(it, 1, 6272, 1, None, 0, None) == -2      # M = 128 is not a multiple of 256
     assert b"wgrad_group" in lib.segclip_last_error_string()
+
+
+def test_half_tile_tail_plan():
+    """gemm_bf16_pq.hip: the tiles of a last round that is at most half full run as 128 x 256 workgroups"""
+    lib = L.load()
+    assert lib.segclip_gemm_pq_half_tail(197 * 3) == 79        # N = 768 at 256 x 197 rows: 2 full rounds + 79 tiles
+    assert lib.segclip_gemm_pq_half_tail(197 * 12) == 60       # N = 3072: 9 rounds + 60
+    assert lib.segclip_gemm_pq_half_tail(197 * 9) == 0         # N = 2304: the last round has 237 tiles
+    assert lib.segclip_gemm_pq_half_tail(256 + 128) == 128 and lib.segclip_gemm_pq_half_tail(256 + 129) == 0
+    for n in (0, 1, 154, 256, 512):                            # one partial round only / whole rounds: nothing to split
+        assert lib.segclip_gemm_pq_half_tail(n) == 0
