@@ -424,6 +424,13 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    sampler = None
+    if rank == 0:   # shader clock / socket power during the timed region (a reader thread on the host; no GPU work)
+        try:
+            from tools.clock_sampler import ClockSampler, device_bus_id
+            sampler = ClockSampler(device_bus_id(local_rank)).start()
+        except Exception:
+            sampler = None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
@@ -432,6 +439,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    clocks = sampler.stop() if sampler is not None else None
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -577,6 +585,15 @@ def main():
                           "loss": round(loss_val, 5)},
                "parity_mode": parity_mode, "bf16_vs_f32": bf16_vs_f32, "global_batch_2048_single_gpu": gb2048, "text_trim": text_trim,
                "roofline": roofline, "cpu_baseline": cpu}
+        if clocks:
+            # the chip's state during the timed region: under this step the socket sits at its power cap and the shader clock
+            # below the 2.4 GHz the 2.5 PFLOP/s dense-bf16 peak is quoted at; peak_at_clock rescales that peak linearly
+            clocks["note"] = ("amdsmi GFX clock / socket power sampled every 20 ms during the timed region (first fifth dropped); "
+                              "roofline.peak stays the 2.4 GHz figure, peak_bf16_tf_at_sclk = 2500 x sclk / 2400")
+            clocks["peak_bf16_tf_at_sclk"] = round(PEAK_BF16_TF * clocks["sclk_mhz_mean"] / 2400.0, 1)
+            if roofline and roofline.get("achieved"):
+                clocks["roofline_frac_at_sclk"] = round(roofline["achieved"] / clocks["peak_bf16_tf_at_sclk"], 4)
+            out["clocks"] = clocks
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()   # nobody tears the group down while another rank may still be inside a collective

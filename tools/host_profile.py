@@ -8,7 +8,8 @@ from segclip_amd import synth
 segclip_amd.set_compute_dtype(torch.bfloat16)
 spec = synth.SPECS["vitb16"]
 model, _ = synth.build_model(spec, {}, device="cuda")
-b = synth.synthetic_batch(spec, 256, seed=0, device="cuda", with_seg=False)
+B = int(os.environ.get("BATCH", "256"))
+b = synth.synthetic_batch(spec, B, seed=0, device="cuda", with_seg=False)
 
 
 def step():
@@ -27,4 +28,4 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(int(os.environ.get("TOP", "22")))
