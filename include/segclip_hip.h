@@ -442,6 +442,11 @@ int segclip_center_logits_bwd(const float* dl, const float* q, const float* k, f
  * GEMM weights, refreshed once per forward instead of one cast launch per weight).  src/dst/n are HOST arrays. */
 int segclip_multi_cast_bf16(const float* const* src, void* const* dst, const int64_t* n, int64_t count, void* stream);
 
+/* dst[i][:] += src[i][:] for `count` fp32 tensor pairs in ceil(count/32) launches: a parameter used by two passes of one
+ * step (the vision tower runs on the clean and on the masked image when the MAE loss is on, reference modules/modeling.py:
+ * 196,237-249) receives two gradients; autograd would add them with one launch per parameter.  dst/src/n are HOST arrays. */
+int segclip_multi_add_f32(float* const* dst, const float* const* src, const int64_t* n, int64_t count, void* stream);
+
 /* number of fp32 partial sums segclip_grad_sqnorm needs in `ws` for these tensor sizes */
 size_t segclip_grad_sqnorm_ws_bytes(const int64_t* n, int64_t count);
 /* ctrl->grad_sqnorm = sum_i |grads[i]|^2 (deterministic two-level reduction), ctrl->clip_coef as above

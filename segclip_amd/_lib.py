@@ -123,6 +123,7 @@ SIGNATURES = {
     "segclip_mask_sort": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
     "segclip_interp_bicubic": (C.c_int, [vp, vp, i64, i64, i64, i64, vp]),
     "segclip_multi_cast_bf16": (C.c_int, [vp, vp, vp, i64, vp]),
+    "segclip_multi_add_f32": (C.c_int, [vp, vp, vp, i64, vp]),
     "segclip_max_tokens_fwd": (C.c_int, [vp, vp, vp, i64, i64, i64, vp]),
     "segclip_max_tokens_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
     "segclip_l2norm_pair_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, vp]),

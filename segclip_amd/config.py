@@ -56,6 +56,12 @@ text_trim     : training fast path of the text tower (CLIP.encode_text_eot): run
                 77.  OFF by default: bench.py times the reference's full context; the switch exists for real caption data
                 (the published recipe itself trains with max_words 32).  L is read with one host synchronisation whenever the
                 id tensor changes (cached by storage / version); `text_trim_hint` (int) avoids it for callers that know it
+fold_param_grads : a parameter that two nodes of ONE backward pass produce gradients for (the vision tower runs on the clean
+                and on the masked image when the MAE loss is on: reference modules/modeling.py:196,237-249) would have the two
+                summed by the autograd engine, one `aten::add` launch per parameter (~150 per step).  With the switch on,
+                ResStackFn hands autograd the FIRST gradient of a parameter, adds every later one of the same pass into that
+                tensor (one multi-tensor launch per stack, segclip_multi_add_f32) and returns None for it.  Same sums, same
+                order; off while GradSync bucket slots are active
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -70,7 +76,7 @@ import torch
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
-                 text_after_blocks=4, text_trim=False, text_trim_hint=None,
+                 text_after_blocks=4, text_trim=False, text_trim_hint=None, fold_param_grads=__import__("os").environ.get("SEGCLIP_FOLD_GRADS", "1") != "0",
                  wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP_DIST", "12")))
 _tls = threading.local()
 

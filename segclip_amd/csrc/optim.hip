@@ -216,6 +216,32 @@ __global__ __launch_bounds__(kThreads) void multi_cast_bf16_kernel(CastLaunch L)
   for (int64_t i = (nv << 2) + threadIdx.x; i < left; i += kThreads) dst[i] = f2bf(src[i]);
 }
 
+struct AddLaunch {
+  float* dst[kTensorsPerLaunch];
+  const float* src[kTensorsPerLaunch];
+  int64_t n[kTensorsPerLaunch];
+  int32_t first_block[kTensorsPerLaunch + 1];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(kThreads) void multi_add_f32_kernel(AddLaunch L) {
+  const int t = find_tensor(L.first_block, L.count, blockIdx.x);
+  const int64_t base = (int64_t)(blockIdx.x - L.first_block[t]) * kChunk;
+  const int64_t left = L.n[t] - base < kChunk ? L.n[t] - base : kChunk;
+  const float* __restrict__ src = L.src[t] + base;
+  float* __restrict__ dst = L.dst[t] + base;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    const int64_t nv = left >> 2;
+    for (int64_t i = threadIdx.x; i < nv; i += kThreads) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(dst)[i], b = reinterpret_cast<const f32x4*>(src)[i];
+      reinterpret_cast<f32x4*>(dst)[i] = a + b;
+    }
+    for (int64_t i = (nv << 2) + threadIdx.x; i < left; i += kThreads) dst[i] += src[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < left; i += kThreads) dst[i] += src[i];
+  }
+}
+
 int64_t blocks_of(int64_t n) { return cdiv(n, kChunk); }
 
 }  // namespace
@@ -332,5 +358,33 @@ extern "C" int segclip_multi_cast_bf16(const float* const* src, void* const* dst
     hipLaunchKernelGGL(multi_cast_bf16_kernel, dim3(nb), dim3(kThreads), 0, st, L);
   }
   SEGCLIP_CHECK_LAUNCH("segclip_multi_cast_bf16");
+  return 0;
+}
+
+extern "C" int segclip_multi_add_f32(float* const* dst, const float* const* src, const int64_t* n, int64_t count, void* stream) {
+  SEGCLIP_REQUIRE(count == 0 || (src && dst && n), "segclip_multi_add_f32: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i0 = 0; i0 < count;) {
+    AddLaunch L;
+    int c = 0;
+    int32_t nb = 0;
+    for (; i0 < count && c < kTensorsPerLaunch; ++i0) {
+      if (n[i0] <= 0) continue;
+      SEGCLIP_REQUIRE(src[i0] && dst[i0], "segclip_multi_add_f32: null pointer in tensor %lld", (long long)i0);
+      SEGCLIP_REQUIRE(((uintptr_t)src[i0] & 3) == 0 && ((uintptr_t)dst[i0] & 3) == 0,
+                      "segclip_multi_add_f32: tensor %lld is not aligned", (long long)i0);
+      L.dst[c] = dst[i0];
+      L.src[c] = src[i0];
+      L.n[c] = n[i0];
+      L.first_block[c] = nb;
+      nb += (int32_t)blocks_of(n[i0]);
+      ++c;
+    }
+    if (c == 0) continue;
+    for (int j = c; j <= kTensorsPerLaunch; ++j) L.first_block[j] = nb;
+    L.count = c;
+    hipLaunchKernelGGL(multi_add_f32_kernel, dim3(nb), dim3(kThreads), 0, st, L);
+  }
+  SEGCLIP_CHECK_LAUNCH("segclip_multi_add_f32");
   return 0;
 }

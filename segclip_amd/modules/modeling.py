@@ -160,6 +160,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
         image_frame = 1
         if not self.training:
             return None
+        ops._GradFold.advance()          # config.fold_param_grads: nothing of an earlier (possibly failed) backward pass survives
         if config.compute_dtype == torch.bfloat16:
             ops.refresh_weight_shadows(force=not config.trust_weight_shadows)
         # The two towers are independent until the similarity: the text tower (small GEMMs that leave most CUs

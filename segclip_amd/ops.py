@@ -1080,6 +1080,53 @@ class ResBlockFn(Function):
         return (dx,) + grads + (None, None, None, None, None, None)
 
 
+class _GradFold:
+    """config.fold_param_grads: the first gradient a parameter receives in a backward pass is remembered (and goes to autograd
+    as usual: it sits in the engine's input buffer until every producer of that parameter has run); a later gradient of the
+    same pass is added INTO that tensor by one multi-tensor launch per caller and autograd gets None for it.  An entry is
+    valid for one pass: the epoch advances when the pass ends (engine callback) and at every model forward (a backward that
+    raised never ran its callback)."""
+    epoch = 0
+    armed = -1
+    first = {}
+    uses = {}      # id(first parameter of a block) -> ResStackFn forwards over that block since the last advance(): armed from 2
+
+    @classmethod
+    def advance(cls):
+        cls.epoch += 1
+        cls.first.clear()
+        cls.uses.clear()
+
+    @classmethod
+    def take(cls, p, gr, adds):
+        """gr: this node's gradient of parameter p -> what the node returns to autograd for it"""
+        if gr is None or gr.dtype != torch.float32 or not gr.is_contiguous():
+            return gr
+        ent = cls.first.get(id(p))
+        if ent is not None and ent[0] == cls.epoch and ent[1].shape == gr.shape and ent[1].device == gr.device:
+            adds.append((ent[1], gr))
+            return None
+        # an ALIAS of the gradient (same storage, its own TensorImpl): AccumulateGrad takes an incoming gradient over without
+        # a copy only while nothing else references that tensor object - a plain reference here costs one clone per parameter
+        cls.first[id(p)] = (cls.epoch, gr.detach())
+        if cls.armed != cls.epoch:
+            cls.armed = cls.epoch
+            torch.autograd.Variable._execution_engine.queue_callback(cls.advance)
+        return gr
+
+    @staticmethod
+    def flush(adds):
+        if not adds:
+            return
+        n = len(adds)
+        dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in adds])
+        src = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in adds])
+        cnt = (C.c_int64 * n)(*[d.numel() for d, _ in adds])
+        L.check(L.load().segclip_multi_add_f32(C.cast(dst, C.c_void_p), C.cast(src, C.c_void_p), C.cast(cnt, C.c_void_p), n,
+                                               L.stream()), "multi_add_f32")
+        adds.clear()
+
+
 class ResStackFn(Function):
     """N consecutive ResBlockFn blocks as ONE autograd node (the towers: 10 + 2 vision blocks, 12 text blocks).  Inside
     the node the gradients travel between the blocks as plain tensors, so in bf16 mode (config.bf16_resgrad) the
@@ -1116,6 +1163,11 @@ class ResStackFn(Function):
         ctx.chain = (bool(chain) or resid16) and act_dtype == torch.bfloat16
         ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
         ctx.wgrad_group, ctx.wgrad_group_dist = int(_cfg.wgrad_group_blocks), int(_cfg.wgrad_group_blocks_dist)
+        ctx.fold = bool(_cfg.fold_param_grads) and not (ctx.overlap_wgrad or bool(_cfg.reduce_side)) and len(params) > 0
+        if ctx.fold:     # per block (the same blocks may be cut into different stacks by the two passes)
+            for b in range(nblk):
+                k = id(params[b * 12])
+                _GradFold.uses[k] = _GradFold.uses.get(k, 0) + 1
         ctx.params = params
         ctx.slots = tuple(_slot_of(w) for w in params)
         if resid16 and not keep16:
@@ -1160,6 +1212,7 @@ class ResStackFn(Function):
         left = sizes.pop(0) if wg is not None else 0
         grq = ReduceQueue() if (wg is not None and rside is None and _SHARED_RQ) else None
         pending = []
+        adds = []
         for b in reversed(range(nblk)):
             P = ctx.params[b * 12:(b + 1) * 12]
             sl = ctx.slots[b * 12:(b + 1) * 12]
@@ -1178,6 +1231,7 @@ class ResStackFn(Function):
                     grq.flush()
                 left = sizes.pop(0) if sizes else nblk
             for b_, P_, sl_, grads_ in pending:
+                fold = ctx.fold and _GradFold.uses.get(id(P_[0]), 0) > 1      # only blocks a second node of this pass shares
                 for i, (p, gr, slot) in enumerate(zip(P_, grads_, sl_)):
                     if gr is None:
                         continue
@@ -1186,9 +1240,12 @@ class ResStackFn(Function):
                         # zero-copy gradient inside its all-reduce bucket: publish it now (autograd gets None for it)
                         p.grad = gr
                         owner._on_grad(p)
+                    elif fold and slot is None:
+                        out[b_ * 12 + i] = _GradFold.take(p, gr, adds)
                     else:
                         out[b_ * 12 + i] = gr
             pending = []
+        _GradFold.flush(adds)
         if keep is not None:
             torch.cuda.current_stream().wait_stream(_wgrad_stream())
             keep.clear()

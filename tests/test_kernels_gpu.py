@@ -686,6 +686,58 @@ def test_res_stack_matches_block_by_block(dtype, causal):
             assert rel <= 2e-2, rel
 
 
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_res_stack_folds_gradients_of_shared_parameters(dtype):
+    """config.fold_param_grads: the same blocks applied to two inputs in ONE graph (the vision tower on the clean and on the
+    masked image, reference modules/modeling.py:196,237-249): the second node adds its parameter gradients into the first
+    node's tensors (segclip_multi_add_f32) and returns None, instead of one aten::add per parameter inside the autograd
+    engine.  Gradients must be the bits of the engine's sums; a second pass (fresh epoch) and accumulation into existing
+    .grad tensors must still work."""
+    import segclip_amd
+    B, D, H, nblk = 2, 128, 4, 2
+    torch.manual_seed(11)
+    blocks = []
+    for _ in range(nblk):
+        P = [torch.ones(D) + 0.1 * torch.randn(D), 0.1 * torch.randn(D), torch.randn(3 * D, D) * D ** -0.5,
+             0.1 * torch.randn(3 * D), torch.randn(D, D) * D ** -0.5, 0.1 * torch.randn(D),
+             torch.ones(D) + 0.1 * torch.randn(D), 0.1 * torch.randn(D), torch.randn(4 * D, D) * D ** -0.5,
+             0.1 * torch.randn(4 * D), torch.randn(D, 4 * D) * (4 * D) ** -0.5, 0.1 * torch.randn(D)]
+        blocks.append([p.to(DEV).requires_grad_() for p in P])
+    xa, xb = torch.randn(B, 40, D, device=DEV), torch.randn(B, 24, D, device=DEV)     # two token counts, like the masked pass
+    ga, gb = torch.randn(B, 40, D, device=DEV), torch.randn(B, 24, D, device=DEV)
+    folded = []
+    real_flush = ops._GradFold.flush
+
+    def counting_flush(adds):
+        folded.append(len(adds))
+        return real_flush(adds)
+
+    def run(fold, keep_grads=False):
+        if not keep_grads:
+            for P in blocks:
+                for p in P:
+                    p.grad = None
+        with segclip_amd.config.scope(fold_param_grads=fold):
+            ya = ops.res_stack(xa, blocks, H, False, ops.ACT_QUICK_GELU, 1e-5, dtype)
+            yb = ops.res_stack(xb, blocks, H, False, ops.ACT_QUICK_GELU, 1e-5, dtype)
+            ((ya * ga).sum() + (yb * gb).sum()).backward()
+        return [[p.grad.clone() for p in P] for P in blocks]
+
+    ref = run(False)
+    ops._GradFold.flush = staticmethod(counting_flush)
+    try:
+        got = run(True)
+        assert sum(folded) == 12 * nblk, folded            # every parameter's second gradient was folded, none left to the engine
+        again = run(True)                                  # next pass: a fresh epoch, nothing stale
+        twice = run(True, keep_grads=True)                 # .grad exists: AccumulateGrad adds the (folded) sum to it
+    finally:
+        ops._GradFold.flush = staticmethod(real_flush)
+    for a, b, c, d in zip(ref, got, again, twice):
+        for u, v, w, z in zip(a, b, c, d):
+            assert torch.equal(u, v) and torch.equal(u, w)
+            assert torch.allclose(z, 2 * u, rtol=1e-6, atol=1e-6)
+
+
 def test_res_stack_bf16_chain_depth12_width768():
     """The bf16 residual-gradient chain (config.bf16_resgrad, the mode the bench runs) at the DEPTH and WIDTH of the
     vision tower: 12 blocks, D = 768, against the same stack with the fp32 residual gradient and against the exact-f32
