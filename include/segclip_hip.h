@@ -499,6 +499,8 @@ int segclip_wgrad_group(const segclip_wgrad_item* items, int n, int64_t R, int s
  * at most half full (ntiles > 256, 0 < ntiles % 256 <= 128: out_proj / c_proj and the data gradients of in_proj / c_fc at
  * 256 x 197 token rows are 591 tiles) runs those tail tiles as twice as many 128 x 256 workgroups.  Results are bit-identical
  * to the full tiles'.  Returns the number of tail tiles run that way (0 = none; SEGCLIP_PQ_HALF=0 disables it).
+ * The same half-tile workgroups cover a last row of 128 token rows: M = 256 q + 128 (128 samples x 197 / 577 / 77 tokens)
+ * runs on this kernel as q rows of full tiles + N / 256 half-tiles.
  * ------------------------------------------------------------------------------------------ */
 int segclip_gemm_pq_half_tail(int64_t ntiles);
 

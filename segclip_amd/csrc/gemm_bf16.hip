@@ -478,7 +478,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   bool launched = false;
   if (d->colsum) {
     SEGCLIP_REQUIRE(d->colsum_ws != nullptr, "gemm: colsum needs colsum_ws");
-    if (!(want_dma(d) && d->M % 256 == 0 && d->N % 256 == 0 && g.splits == 1 && nb == 1)) {
+    if (!(want_dma(d) && d->M % 128 == 0 && d->N % 256 == 0 && g.splits == 1 && nb == 1)) {
       segclip_set_error("gemm: fused colsum unsupported for this shape");
       return SEGCLIP_ERR_UNSUPPORTED;
     }

@@ -72,6 +72,8 @@ struct PQArgs {
   // half-tile tail (every mode but PQ_SLAB): the half_r tiles of the last, partial round of 256 workgroups run as
   // 2 * half_r workgroups of 128 x 256 (workgroups nfull ..: the upper / lower 128 rows of tile nfull + j / 2)
   int half_r;
+  // remainder row: M = 256 q + 128 -> half_x = nbx more half-tile workgroups (the upper halves of tile row q), behind the tail's
+  int half_x;
   int abl;               // timing experiments (SEGCLIP_PQ_ABL, results garbage): 1 = no output stores, 2 = no epilogue at all
 };
 
@@ -535,15 +537,20 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
   constexpr bool HALF_OK = MODE != PQ_SLAB;
   bool half = false;
   int hsel = 0;
-  if (HALF_OK && !A_KS && g.half_r > 0) {
+  if (HALF_OK && !A_KS && (g.half_r > 0 || g.half_x > 0)) {
     if (bid >= g.nfull) {
-      const int j = bid - g.nfull, n2 = 2 * g.half_r, q8h = n2 >> 3, r8h = n2 & 7;
-      const int hu = (xcd < r8h ? xcd * (q8h + 1) : r8h * (q8h + 1) + (xcd - r8h) * q8h) + (j >> 3);
-      unit = g.nfull + (hu >> 1);
-      hsel = hu & 1;
+      const int j = bid - g.nfull, n2 = 2 * g.half_r + g.half_x, q8h = n2 >> 3, r8h = n2 & 7, xh = j & 7;
+      const int hu = (xh < r8h ? xh * (q8h + 1) : r8h * (q8h + 1) + (xh - r8h) * q8h) + (j >> 3);
+      if (hu < 2 * g.half_r) {
+        unit = g.nfull + (hu >> 1);
+        hsel = hu & 1;
+      } else {
+        unit = g.nfull + g.half_r + (hu - 2 * g.half_r);   // tile row M / 256: only its upper 128 rows exist
+      }
       half = true;
     } else {
-      unit = xcd * (g.nfull >> 3) + (bid >> 3);   // nfull is a multiple of 256
+      const int q8f = g.nfull >> 3, r8f = g.nfull & 7;
+      unit = (xcd < r8f ? xcd * (q8f + 1) : r8f * (q8f + 1) + (xcd - r8f) * q8f) + (bid >> 3);
     }
   }
   const int ksplit = MODE == PQ_SLAB ? unit / g.ntiles : 0;
@@ -984,10 +991,12 @@ static int pq_tail_plan(int64_t ntiles, int64_t nkt, int* r_out) {
 // one round (r <= 128): 591 tiles (N = 768 at M = 50432) are 2.3 rounds of 256 CUs and take the time of 3; the third round
 // then costs a half-tile's time (about 0.6 of a tile's: 3 of 4 operand units per K-tile, half the MFMAs, half the output).
 // No exchange between workgroups, results bit-identical to the full tiles'.  SEGCLIP_PQ_HALF=0 switches it off (A/B).
-static int pq_half_plan(int64_t ntiles) {
+static bool pq_half_on() {
   static const int env = [] { const char* e = getenv("SEGCLIP_PQ_HALF"); return e ? atoi(e) : 1; }();
-  const int now = env == 2 ? [] { const char* e = getenv("SEGCLIP_PQ_HALF_NOW"); return e ? atoi(e) : 1; }() : env;
-  if (!now || ntiles <= 256) return 0;
+  return (env == 2 ? [] { const char* e = getenv("SEGCLIP_PQ_HALF_NOW"); return e ? atoi(e) : 1; }() : env) != 0;
+}
+static int pq_half_plan(int64_t ntiles) {
+  if (!pq_half_on() || ntiles <= 256) return 0;
   const int r = (int)(ntiles % 256);
   return r > 0 && r <= 128 ? r : 0;
 }
@@ -1008,11 +1017,14 @@ static bool pq_tail_setup(PQArgs& g, const segclip_gemm_desc* d, hipStream_t str
   int r = 0;
   const int S = pq_tail_plan(g.ntiles, g.K / BK, &r);
   *nwg = (unsigned)g.ntiles;
-  if (!S && allow_half) {
+  const int hx = d->M % BT != 0 ? g.nbx : 0;      // M = 256 q + 128 (checked by the caller): one more row of half-tiles
+  if (hx && !pq_half_on()) return false;
+  if ((!S || hx) && allow_half) {
     const int hr = pq_half_plan(g.ntiles);
-    if (hr > 0) { g.half_r = hr; g.nfull = g.ntiles - hr; *nwg = (unsigned)(g.nfull + 2 * hr); }
+    if (hr > 0 || hx > 0) { g.half_r = hr; g.half_x = hx; g.nfull = g.ntiles - hr; *nwg = (unsigned)(g.nfull + 2 * hr + hx); }
     return true;
   }
+  if (hx) return false;
   if (!S || d->ws == nullptr || (size_t)d->ws_bytes < pq_tail_ws_bytes(r, S) || (reinterpret_cast<uintptr_t>(d->ws) & 15) != 0) return true;
   if (hipMemsetAsync(d->ws, 0, 4096, stream) != hipSuccess) return false;
   g.tail_S = S; g.tail_r = r; g.nfull = g.ntiles - r;
@@ -1035,7 +1047,9 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   const Args& a = *reinterpret_cast<const Args*>(args_);
   const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
   if (nb != 1 || d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16) return false;
-  if (d->M % BT != 0 || d->N % BT != 0 || d->K % BK != 0 || d->K < BK) return false;
+  // M = 256 q + 128 (the token rows of an odd multiple of 128 samples x 197 / 577 / 77 tokens): the last 128 rows run as a
+  // row of half-tiles (forward / data-gradient layouts; the weight gradient's M is a weight dimension)
+  if (d->M % (a_ks ? BT : 128) != 0 || d->M < 128 || d->N % BT != 0 || d->K % BK != 0 || d->K < BK) return false;
   if (a_ks) {   // weight gradient: C(m,n) = sum_k A[k][m] B[k][n], fp32 out (split-K: raw partial tiles into the slabs)
     static const int wg_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ_WGRAD"); return e ? atoi(e) : 1; }();
     if (!wg_env || !b_ks || d->c_dtype != SEGCLIP_F32) return false;

@@ -344,7 +344,7 @@ def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_d
 
 def fused_colsum_ok(M, N, K, dtype):
     """Shapes for which the bf16 LDS-DMA GEMM can emit the column sums of its output in the epilogue."""
-    return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0
+    return dtype == torch.bfloat16 and M % 128 == 0 and N % 256 == 0 and K % 64 == 0     # (128: a last row of half-tiles)
 
 
 def p_dgrad(dy, w, out_dtype, aux=None, act=ACT_NONE, w_kn=False, want_colsum=False, colsum_out=None, aux_kind=0, defer=None,
@@ -925,11 +925,11 @@ N_SAVED = 19
 def _aux_kind(act_dtype, act, M=0, N=0):
     """What the residual blocks keep of the MLP pre-activation: act'(u) in bf16 mode with QuickGELU (the towers) - as one
     byte per element (aux_kind 2, config.aux_u8: half the bytes of the block's largest side tensor; absolute error
-    <= 0.0025) when the GEMM runs on full 256 x 256 tiles, else as bf16 -, u itself in the exact-f32 mode and for the
+    <= 0.0025) when the GEMM runs on 256 x 256 tiles (rows a multiple of 128), else as bf16 -, u itself in the exact-f32 mode and for the
     erf-GELU of the MAE decoders."""
     if act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU:
         from . import config as _cfg
-        return 2 if (_cfg.aux_u8 and M > 0 and M % 256 == 0 and N % 256 == 0) else 1
+        return 2 if (_cfg.aux_u8 and M > 0 and M % 128 == 0 and N % 256 == 0) else 1
     return 0
 
 
@@ -1499,7 +1499,7 @@ class PatchEmbedFn(Function):
         x = _empty((B, T, D), torch.float32, image)
         posc = pos.detach().contiguous()
         done = False
-        if act_dtype == torch.bfloat16 and (B * T) % 256 == 0 and D % 256 == 0:
+        if act_dtype == torch.bfloat16 and (B * T) % 128 == 0 and D % 256 == 0:
             # one (B*T, D) GEMM whose epilogue adds positional row (m % T) - the batched form below runs B problems of T = 196
             # rows on 256-row tiles (289 us against 105 us at B = 256)
             try:

@@ -193,6 +193,38 @@ def test_gemm_half_tile_tail_is_bit_identical(K):
     close(whole[1], whole[0].float().sum(0), 2e-3, 2e-2 * M ** 0.5, "fused column sums")
 
 
+@pytest.mark.parametrize("K", [64, 320])
+def test_gemm_row_remainder_of_128_runs_as_half_tiles(K):
+    """M = 256 q + 128 (an odd multiple of 128 samples x 197 tokens): the 256 x 256-tile kernel covers the last 128 rows with a
+    row of half-tile workgroups.  Every epilogue against the same rows of a launch over 256 (q + 1) rows (one round of full
+    tiles, same kernel): bit-identical; the one-byte derivative and the fused column sums are available on such shapes."""
+    M2, N = 85 * 256, 768
+    M = M2 - 128
+    x, w, b = rnd(M2, K, dtype=BF, seed=91), rnd(N, K, dtype=BF, seed=92, scale=K ** -0.5), rnd(N, seed=93)
+    wk = rnd(K, N, dtype=BF, seed=94, scale=K ** -0.5)
+    r32 = rnd(M2, N, seed=95, scale=3.0)
+    G = ops.ACT_QUICK_GELU
+
+    def same(fn, what):
+        big, part = fn(M2), fn(M)
+        big = big if isinstance(big, tuple) else (big,)
+        part = part if isinstance(part, tuple) else (part,)
+        for t, u in zip(big, part):
+            assert u.shape[0] == M and torch.equal(t[:M], u), what
+        return part
+
+    y = same(lambda m: ops.p_linear(x[:m], w, b)[0], "bias")[0]
+    close(y, x[:M].float() @ w.float().t() + b, 2e-2, 2e-2, "bias epilogue vs fp32 torch")
+    same(lambda m: ops.p_linear(x[:m], w, b, residual=r32[:m], out_dtype=F32)[0], "fp32 residual")
+    same(lambda m: ops.p_dgrad(x[:m], wk, BF), "data gradient")
+    ya, u8 = same(lambda m: tuple(ops.p_linear(x[:m], w, b, act=G, want_aux=True, aux_kind=2)[:2]), "QuickGELU + one-byte derivative")
+    assert u8.dtype == torch.uint8, "the one-byte derivative must be available at M = 256 q + 128"
+    dx, cs = ops.p_dgrad(x[:M], wk, BF, aux=u8, act=G, aux_kind=2, want_colsum=True)
+    dx2, _ = ops.p_dgrad(x, wk, BF, aux=torch.cat([u8, u8[:128]], 0), act=G, aux_kind=2, want_colsum=True)
+    assert torch.equal(dx, dx2[:M]), "x derivative"
+    close(cs, dx.float().sum(0), 2e-3, 2e-2 * M ** 0.5, "fused column sums")
+
+
 def test_gemm_bf16_fp32_A_operand_and_splitk():
     """fp32 residual-stream gradients as the A operand of the bf16 kernels; split-K wgrad (M >> tiles)."""
     M, N, K = 6272, 256, 128
