@@ -268,6 +268,19 @@ int segclip_embed_fwd(const int64_t* ids, const float* table, const float* pos, 
 int segclip_embed_bwd(const int64_t* ids, const float* dout, float* dtable, float* dpos, int64_t B,
                       int64_t L, int64_t D, int64_t vocab, void* stream);
 
+/* MAE glue of the full loss, fp32, D a multiple of 4 (reference modules/modeling.py:240-242: mean over the tokens prepended as
+ * the CLS row; modules/module_mae.py:310-314: mask tokens appended, un-shuffled by ids_restore, + positional table).
+ *   mean_cat:      out (B,T+1,D): out[b][0] = mean_t x[b][t], out[b][1+t] = x[b][t];  bwd: dx[b][t] = dout[b][1+t] + dout[b][0] / T
+ *   mae_unshuffle: out (B,L,D)[b][j] = (ids[b][j] < K ? x[b][ids[b][j]] : mask_token) + pos[j]   (x (B,K,D), ids a permutation of 0..L-1
+ *                  per sample); bwd: dx (B,K,D), dpos (L,D) = sum_b dout, mpart (L,D) = the mask-token share of that sum per
+ *                  position - the mask token's gradient is the column sum of mpart (segclip_colsum). */
+int segclip_mean_cat_fwd(const float* x, float* out, int64_t B, int64_t T, int64_t D, void* stream);
+int segclip_mean_cat_bwd(const float* dout, float* dx, int64_t B, int64_t T, int64_t D, void* stream);
+int segclip_mae_unshuffle_fwd(const float* x, const float* mask_token, const int64_t* ids, const float* pos, float* out, int64_t B,
+                              int64_t K, int64_t L, int64_t D, void* stream);
+int segclip_mae_unshuffle_bwd(const float* dout, const int64_t* ids, float* dx, float* dpos, float* mpart, int64_t B, int64_t K,
+                              int64_t L, int64_t D, void* stream);
+
 /* Row gather / scatter-add with int64 indices (EOT pick modules/module_clip.py:136, MAE keep /
  * un-shuffle gathers modules/module_clip_util.py:110, modules/module_mae.py:310).
  * gather: out[b, j, :] = src[b, idx[b,j], :] ; scatter_add: dsrc[b, idx[b,j], :] += dout[b, j, :]

@@ -312,6 +312,67 @@ __global__ void gather_rows_kernel(const void* __restrict__ src, const int64_t* 
   }
 }
 
+// ---------------------------------------------------------------- MAE glue (reference modules/modeling.py:240-242, modules/module_mae.py:310-314)
+// mean-CLS concat: out[b][0][:] = mean_t x[b][t][:], out[b][1+t][:] = x[b][t][:].  One wave per (sample, 256-column chunk):
+// the token loop is the reduction, so the sum has one fixed order.
+__global__ __launch_bounds__(64) void mean_cat_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int D4, int chunks) {
+  const int b = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + threadIdx.x;
+  if (c >= D4) return;
+  const f32x4* xs = reinterpret_cast<const f32x4*>(x) + (int64_t)b * T * D4 + c;
+  f32x4* os = reinterpret_cast<f32x4*>(out) + (int64_t)b * (T + 1) * D4 + c;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) {
+    const f32x4 v = xs[(int64_t)t * D4];
+    acc += v;
+    os[(int64_t)(t + 1) * D4] = v;
+  }
+  const float inv = 1.0f / (float)T;
+  os[0] = acc * f32x4{inv, inv, inv, inv};
+}
+// dx[b][t][:] = dout[b][1+t][:] + dout[b][0][:] / T
+__global__ void mean_cat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int64_t B, int T, int D4) {
+  const int64_t total = B * T * D4;
+  const float inv = 1.0f / (float)T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t bt = i / D4, b = bt / T, t = bt % T;
+    const f32x4* dr = reinterpret_cast<const f32x4*>(dout) + (b * (T + 1)) * D4 + c;
+    reinterpret_cast<f32x4*>(dx)[i] = dr[(t + 1) * (int64_t)D4] + dr[0] * f32x4{inv, inv, inv, inv};
+  }
+}
+// decoder input: out[b][j][:] = (ids[b][j] < K ? x[b][ids[b][j]][:] : mask_token[:]) + pos[j][:]
+//   = gather(cat([x, mask_token.expand(B, L - K, D)], 1), ids) + pos  without the concatenated tensor
+__global__ void mae_unshuffle_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask_token, const int64_t* __restrict__ ids,
+                                         const float* __restrict__ pos, float* __restrict__ out, int64_t B, int K, int L, int D4) {
+  const int64_t total = B * L * D4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t bj = i / D4, b = bj / L, j = bj % L;
+    const int64_t id = ids[bj];
+    const f32x4 v = id < K ? reinterpret_cast<const f32x4*>(x)[(b * K + (id < 0 ? 0 : id)) * D4 + c] : reinterpret_cast<const f32x4*>(mask_token)[c];
+    reinterpret_cast<f32x4*>(out)[i] = v + reinterpret_cast<const f32x4*>(pos)[j * D4 + c];
+  }
+}
+// backward: one wave per (position j, 256-column chunk) walks the samples: dx[b][ids[b][j]][:] = dout[b][j][:] (kept tokens: ids is
+// a permutation per sample, every kept row is written exactly once), dpos[j][:] = sum_b dout[b][j][:], mpart[j][:] = the part of
+// that sum that belongs to mask tokens (the caller sums mpart over j for the mask token's gradient).  Fixed summation order.
+__global__ __launch_bounds__(64) void mae_unshuffle_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ ids, float* __restrict__ dx,
+                                                               float* __restrict__ dpos, float* __restrict__ mpart, int64_t B, int K, int L, int D4,
+                                                               int chunks) {
+  const int j = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + threadIdx.x;
+  if (c >= D4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t b = 0; b < B; ++b) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(dout)[(b * L + j) * D4 + c];
+    const int64_t id = ids[b * L + j];
+    s += g;
+    if (id < K) reinterpret_cast<f32x4*>(dx)[(b * K + (id < 0 ? 0 : id)) * D4 + c] = g;
+    else m += g;
+  }
+  reinterpret_cast<f32x4*>(dpos)[(int64_t)j * D4 + c] = s;
+  reinterpret_cast<f32x4*>(mpart)[(int64_t)j * D4 + c] = m;
+}
+
 // ---------------------------------------------------------------- learnable-center assignment
 // logits (B,G,T).  One thread per (b,t).  counts accumulated with exact integer-valued float atomics.
 __global__ void assign_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel, float tau,
@@ -698,6 +759,40 @@ extern "C" int segclip_scatter_rows(const void* dout, const int64_t* idx, void* 
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(B * To * D)), dim3(TPB), 0, ST, dout, idx, dsrc, B, (int)Ts, (int)To,
                      (int)D, dt, 1);
   SEGCLIP_CHECK_LAUNCH("scatter_rows");
+  return 0;
+}
+extern "C" int segclip_mean_cat_fwd(const float* x, float* out, int64_t B, int64_t T, int64_t D, void* stream) {
+  SEGCLIP_REQUIRE(D % 4 == 0 && T > 0, "mean_cat: D=%lld must be a multiple of 4, T=%lld positive", (long long)D, (long long)T);
+  if (B == 0) return 0;
+  const int D4 = (int)(D / 4), chunks = (D4 + 63) / 64;
+  hipLaunchKernelGGL(mean_cat_fwd_kernel, dim3((unsigned)(B * chunks)), dim3(64), 0, ST, x, out, (int)T, D4, chunks);
+  SEGCLIP_CHECK_LAUNCH("mean_cat_fwd");
+  return 0;
+}
+extern "C" int segclip_mean_cat_bwd(const float* dout, float* dx, int64_t B, int64_t T, int64_t D, void* stream) {
+  SEGCLIP_REQUIRE(D % 4 == 0 && T > 0, "mean_cat: D=%lld must be a multiple of 4, T=%lld positive", (long long)D, (long long)T);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(mean_cat_bwd_kernel, dim3(grid1d(B * T * (D / 4))), dim3(TPB), 0, ST, dout, dx, B, (int)T, (int)(D / 4));
+  SEGCLIP_CHECK_LAUNCH("mean_cat_bwd");
+  return 0;
+}
+extern "C" int segclip_mae_unshuffle_fwd(const float* x, const float* mask_token, const int64_t* ids, const float* pos, float* out,
+                                         int64_t B, int64_t K, int64_t L, int64_t D, void* stream) {
+  SEGCLIP_REQUIRE(D % 4 == 0 && K <= L, "mae_unshuffle: D=%lld must be a multiple of 4 and K=%lld <= L=%lld", (long long)D, (long long)K, (long long)L);
+  if (B * L == 0) return 0;
+  hipLaunchKernelGGL(mae_unshuffle_fwd_kernel, dim3(grid1d(B * L * (D / 4))), dim3(TPB), 0, ST, x, mask_token, ids, pos, out, B, (int)K,
+                     (int)L, (int)(D / 4));
+  SEGCLIP_CHECK_LAUNCH("mae_unshuffle_fwd");
+  return 0;
+}
+extern "C" int segclip_mae_unshuffle_bwd(const float* dout, const int64_t* ids, float* dx, float* dpos, float* mpart, int64_t B, int64_t K,
+                                         int64_t L, int64_t D, void* stream) {
+  SEGCLIP_REQUIRE(D % 4 == 0 && K <= L, "mae_unshuffle: D=%lld must be a multiple of 4 and K=%lld <= L=%lld", (long long)D, (long long)K, (long long)L);
+  if (L == 0) return 0;
+  const int D4 = (int)(D / 4), chunks = (D4 + 63) / 64;
+  hipLaunchKernelGGL(mae_unshuffle_bwd_kernel, dim3((unsigned)(L * chunks)), dim3(64), 0, ST, dout, ids, dx, dpos, mpart, B, (int)K, (int)L, D4,
+                     chunks);
+  SEGCLIP_CHECK_LAUNCH("mae_unshuffle_bwd");
   return 0;
 }
 extern "C" int segclip_assign_fwd(const float* logits, const float* gumbel, float tau, float* y_soft, float* soft,

@@ -239,8 +239,7 @@ class SegCLIP(SegCLIPPreTrainedModel):
             _, vis_hidden, vis_mae_mask, vis_mae_ids_restore, mid_mae_states = self.get_visual_output(
                 image, shaped=True, image_frame=image_frame, return_hidden=True, mask_ratio=self.vis_mask_ratio)
             vis_hidden = mid_mae_states["hidden"]
-            cls_ = torch.mean(vis_hidden, dim=1, keepdim=True)
-            vis_hidden = torch.cat([cls_, vis_hidden], dim=1)
+            vis_hidden = ops.mean_cat(vis_hidden)          # cat([mean over the tokens, tokens]) as one kernel
             vis_mae_mask = vis_mae_mask.view(-1, vis_mae_mask.size(-1))
             vis_mae_ids_restore = vis_mae_ids_restore.view(-1, vis_mae_ids_restore.size(-1))
             self.last_mae = _detached((vis_mae_mask, vis_mae_ids_restore, mid_mae_states))

@@ -143,6 +143,17 @@ class MAEDecoder(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def _unshuffle(self, x, ids_restore):
+        """modules/module_mae.py:310-314 / 338-342: append mask tokens, un-shuffle, add the positional table - one kernel
+        (ops.MaeUnshuffleFn) where its preconditions hold, the op-by-op form otherwise."""
+        B, Kk, Dd = x.shape
+        Lq = ids_restore.shape[1]
+        if (x.dtype == torch.float32 and Dd % 4 == 0 and ids_restore.dtype == torch.int64 and Kk <= Lq
+                and self.decoder_pos_embed.shape[-2] == Lq):
+            return ops.MaeUnshuffleFn.apply(x, self.mask_token, ids_restore, self.decoder_pos_embed)
+        x_ = torch.cat([x, self.mask_token.float().expand(B, Lq - Kk, Dd)], dim=1)
+        return ops.GatherRowsFn.apply(x_, ids_restore) + self.decoder_pos_embed.float()
+
     def forward_vis(self, image, vis_hidden, vis_mae_mask, vis_mae_ids_restore, loss_allpatch=False):
         if loss_allpatch:
             raise NotImplementedError("loss_allpatch=True is never used by the reference forward")
@@ -151,11 +162,7 @@ class MAEDecoder(nn.Module):
         Lq = vis_mae_ids_restore.shape[1]
         x = ops.linear(vis_hidden.float(), self.decoder_embed.weight, self.decoder_embed.bias, out_dtype=torch.float32,
                        act_dtype=ad)
-        Dd = x.shape[-1]
-        mask_tokens = self.mask_token.float().expand(B, Lq - Kk, Dd)
-        x_ = torch.cat([x, mask_tokens], dim=1)
-        x = ops.GatherRowsFn.apply(x_, vis_mae_ids_restore)
-        x = x + self.decoder_pos_embed.float()
+        x = self._unshuffle(x, vis_mae_ids_restore)
         for blk in self.decoder_blocks:
             x = blk(x)
         x = ops.layer_norm(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps, ad)
@@ -172,10 +179,7 @@ class MAEDecoder(nn.Module):
         Lq = seq_mae_ids_restore.shape[1]
         x = ops.linear(seq_hidden.float(), self.decoder_embed.weight, self.decoder_embed.bias, out_dtype=torch.float32,
                        act_dtype=ad)
-        Dd = x.shape[-1]
-        x_ = torch.cat([x, self.mask_token.float().expand(B, Lq - Kk, Dd)], dim=1)
-        x = ops.GatherRowsFn.apply(x_, seq_mae_ids_restore)
-        x = x + self.decoder_pos_embed.float()
+        x = self._unshuffle(x, seq_mae_ids_restore)
         key_len = ops.prefix_mask_lengths(attention_mask)
         for blk in self.decoder_blocks:
             x = blk(x, key_len)

@@ -379,8 +379,7 @@ class SegViT(nn.Module):
             x_ = self.reconstruct_layer2(sx_, hard_attn_2)
             x_ = self._run_blocks(self.layers_mae2, x_)
             mid_states["hidden"] = x_
-            cls = torch.mean(x_, dim=1, keepdim=True)
-            x = torch.cat([cls, x_], dim=1)
+            x = ops.mean_cat(x_)
         else:
             mid_states["hidden"] = x_
             x_, hard_attn_2, soft_attn_2, _ = self.semantic_layer2(x_)

@@ -1567,6 +1567,69 @@ class EmbedFn(Function):
         return None, dtable, dpos
 
 
+class MeanCatFn(Function):
+    """cat([mean(x, dim=1, keepdim=True), x], dim=1) for x (B,T,D) fp32 (reference modules/modeling.py:240-242 and the MAE branch
+    of modules/module_seg_vit.py: the mean over the tokens stands in for the CLS row): one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, T, D = x.shape
+        x = x.contiguous()
+        out = _empty((B, T + 1, D), torch.float32, x)
+        L.check(L.load().segclip_mean_cat_fwd(L.ptr(x), L.ptr(out), B, T, D, L.stream()), "mean_cat_fwd")
+        ctx.shape = (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, D = ctx.shape
+        dout = dout.contiguous()
+        dx = _empty((B, T, D), torch.float32, dout)
+        L.check(L.load().segclip_mean_cat_bwd(L.ptr(dout), L.ptr(dx), B, T, D, L.stream()), "mean_cat_bwd")
+        return dx
+
+
+def mean_cat(x):
+    """x (B,T,D) -> (B,T+1,D) with the token mean as row 0; fp32 rows of a multiple of 4 columns on the HIP kernel."""
+    if x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] % 4 == 0 and x.shape[1] > 0:
+        return MeanCatFn.apply(x)
+    return torch.cat([torch.mean(x, dim=1, keepdim=True), x], dim=1)
+
+
+class MaeUnshuffleFn(Function):
+    """Decoder input of the MAE heads (reference modules/module_mae.py:310-314 / 338-342):
+    gather(cat([x, mask_token.expand(B, L - K, D)], 1), ids_restore) + pos_embed, without the concatenated tensor:
+    out[b][j] = (ids[b][j] < K ? x[b][ids[b][j]] : mask_token) + pos[j].  x (B,K,D) fp32, mask_token (D) or (1,1,D), ids (B,L)
+    int64 (a permutation of 0..L-1 per sample), pos (L,D) or (1,L,D)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_token, ids, pos):
+        B, K, D = x.shape
+        Lq = ids.shape[1]
+        x, ids = x.contiguous(), ids.contiguous()
+        mt, pe = mask_token.detach().reshape(D).float().contiguous(), pos.detach().reshape(Lq, D).float().contiguous()
+        out = _empty((B, Lq, D), torch.float32, x)
+        L.check(L.load().segclip_mae_unshuffle_fwd(L.ptr(x), L.ptr(mt), L.ptr(ids), L.ptr(pe), L.ptr(out), B, K, Lq, D, L.stream()),
+                "mae_unshuffle_fwd")
+        ctx.save_for_backward(ids)
+        ctx.dims = (B, K, Lq, D, mask_token.shape, pos.shape, mask_token.dtype, pos.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        B, K, Lq, D, mshape, pshape, mdt, pdt = ctx.dims
+        dout = dout.contiguous()
+        dx = _empty((B, K, D), torch.float32, dout)
+        dpos = _empty((Lq, D), torch.float32, dout)
+        mpart = _empty((Lq, D), torch.float32, dout)
+        L.check(L.load().segclip_mae_unshuffle_bwd(L.ptr(dout), L.ptr(ids), L.ptr(dx), L.ptr(dpos), L.ptr(mpart), B, K, Lq, D, L.stream()),
+                "mae_unshuffle_bwd")
+        dmask = p_colsum(mpart) if ctx.needs_input_grad[1] else None
+        return (dx, dmask.reshape(mshape).to(mdt) if dmask is not None else None, None,
+                dpos.reshape(pshape).to(pdt) if ctx.needs_input_grad[3] else None)
+
+
 class GatherRowsFn(Function):
     """out[b,j,:] = src[b, idx[b,j], :] with unique idx per b (EOT pick, MAE keep / un-shuffle)."""
 

@@ -635,6 +635,47 @@ def test_superpixel_kl_and_masked_mse():
     close(pred.grad, pr.grad, 1e-4, 1e-7, "mse grad")
 
 
+@pytest.mark.parametrize("B,T,D", [(3, 49, 768), (2, 7, 36), (4, 196, 384)])
+def test_mean_cls_concat(B, T, D):
+    """cat([mean(x, 1, keepdim), x], 1) (reference modules/modeling.py:240-242) as one kernel each way."""
+    x = rnd(B, T, D, seed=201).requires_grad_()
+    g = rnd(B, T + 1, D, seed=202)
+    y = ops.mean_cat(x)
+    y.backward(g)
+    xr = x.detach().clone().requires_grad_()
+    yr = torch.cat([torch.mean(xr, dim=1, keepdim=True), xr], dim=1)
+    yr.backward(g)
+    assert torch.equal(y[:, 1:], yr[:, 1:])
+    close(y[:, 0], yr[:, 0], 1e-6, 1e-6, "token mean")
+    close(x.grad, xr.grad, 1e-6, 1e-6, "mean-cat backward")
+
+
+@pytest.mark.parametrize("B,K,L,D", [(5, 50, 197, 384), (3, 20, 77, 512), (2, 4, 4, 8)])
+def test_mae_unshuffle(B, K, L, D):
+    """gather(cat([x, mask_token.expand(B, L - K, D)], 1), ids_restore) + pos (reference modules/module_mae.py:310-314): forward
+    bit-equal to the op-by-op expression, gradients of x exact (a permutation copy), of the mask token and the positional
+    table to fp32 summation order."""
+    g0 = torch.Generator().manual_seed(7)
+    ids = torch.stack([torch.randperm(L, generator=g0) for _ in range(B)]).to(DEV)
+    x = rnd(B, K, D, seed=211).requires_grad_()
+    mt = rnd(1, 1, D, seed=212, scale=0.02).requires_grad_()
+    pos = rnd(1, L, D, seed=213).requires_grad_()
+    g = rnd(B, L, D, seed=214)
+    y = ops.MaeUnshuffleFn.apply(x, mt, ids, pos)
+    y.backward(g)
+    xr, mr, pr = (t.detach().clone().requires_grad_() for t in (x, mt, pos))
+    cat = torch.cat([xr, mr.expand(B, L - K, D)], dim=1)
+    yr = torch.gather(cat, 1, ids.unsqueeze(-1).expand(B, L, D)) + pr
+    yr.backward(g)
+    assert torch.equal(y, yr)
+    assert torch.equal(x.grad, xr.grad)
+    close(pos.grad, pr.grad, 1e-5, 1e-5, "positional-table gradient")
+    if L > K:
+        close(mt.grad, mr.grad, 1e-5, 1e-4, "mask-token gradient")
+    else:
+        assert float(mt.grad.abs().max()) == 0.0
+
+
 def test_mask_sort_bit_exact():
     B, Lq = 6, 197
     g = torch.Generator().manual_seed(3)

@@ -10,7 +10,9 @@ F='^RCCL\|^HIP\|^ROCm\|Hostname\|Librccl\|amdgpu.ids\|socket.cpp\|ProcessGroupNC
 SEGCLIP_BENCH_PROFILE_DIR=$OUT/rl timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
 cp $OUT/rl/kernel_stats.txt $OUT/kernel_stats.txt
 cp $OUT/rl/intervals.json $OUT/bench_intervals.json 2>/dev/null
-python tools/stream_gaps.py $(ls $OUT/rl/trace/*.db $OUT/rl/trace/*/*.db 2>/dev/null | head -1) 120 > $OUT/stream_gaps.txt 2>&1
+DB=$(ls $OUT/rl/trace/*.db $OUT/rl/trace/*/*.db 2>/dev/null | head -1)
+python tools/stream_gaps.py $DB 120 > $OUT/stream_gaps.txt 2>&1
+python tools/stream_breakdown.py $DB 6 3 > $OUT/stream_breakdown.txt 2>&1
 rm -rf $OUT/rl/trace $OUT/rl/pmc_*
 b() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "$name: $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$name.json) $(grep -o '"value": [0-9.]*' $OUT/bench_$name.json | head -1)"; }
 b gb2048 --no-cpu-baseline --no-traffic --no-parity-leg --global-batch 2048 --steps 5 --warmup 2
@@ -24,10 +26,17 @@ b vitl14 --no-cpu-baseline --no-traffic --no-parity-leg --spec vitl14_336 --batc
 b text_trim --no-cpu-baseline --no-roofline --no-parity-leg --text-trim
 for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --no-parity-leg --batch $bsz; done
 # same-box A/B of the grouped weight gradients (config.wgrad_group_blocks): one launch per gradient vs the default, twice
+# same-box A/Bs, twice each: the half-tile tail of gemm_bf16_pq.hip (SEGCLIP_PQ_HALF=0 = full tiles only), B = 256 and B = 128
+# (at B = 128 the switch also decides whether M = 256 q + 128 runs on that kernel at all); gradient folding on the full loss
 for rep in a b; do
-  SEGCLIP_ATTN_FWD_PF=0 b attn_fwd_old_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
-  b attn_fwd_pf_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
+  SEGCLIP_PQ_HALF=0 b half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
+  b half_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
+  SEGCLIP_PQ_HALF=0 b b128_half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
+  b b128_half_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
+  SEGCLIP_FOLD_GRADS=0 b full_fold_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
+  b full_fold_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
 done
+timeout 400 python tools/bench_pq_half.py 2>&1 | grep -v "$F" | grep -v "^check\|relerr" > $OUT/gemm_half_tile.txt
 timeout 300 python tools/debug/center_stage_profile.py 2>&1 | grep -v "$F" | grep -v "Warning\|warn" > $OUT/center_stage.txt
 timeout 300 python tools/bench_hbm.py 2>&1 | grep -v "$F" > $OUT/hbm_kernels.txt
 timeout 300 python tools/bench_gemm.py 2>&1 | grep -v "$F" > $OUT/gemm_shapes.txt

@@ -39,6 +39,15 @@ for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base o
                 ("attn_fwd_old_a", "SEGCLIP_ATTN_FWD_PF=0 (one workgroup per item attention forward), same box, --steps 30"),
                 ("attn_fwd_pf_a", "default (persistent attention forward), same box, --steps 30"),
                 ("attn_fwd_old_b", "SEGCLIP_ATTN_FWD_PF=0, second pass"), ("attn_fwd_pf_b", "default, second pass"),
+                ("half_off_a", "SEGCLIP_PQ_HALF=0 (full 256 x 256 tiles only), same box, --steps 30"),
+                ("half_on_a", "default (half-tile tail of gemm_bf16_pq.hip), same box, --steps 30"),
+                ("half_off_b", "SEGCLIP_PQ_HALF=0, second pass"), ("half_on_b", "default, second pass"),
+                ("b128_half_off_a", "--batch 128 SEGCLIP_PQ_HALF=0 (M = 256 q + 128 leaves gemm_bf16_pq.hip), same box, --steps 30"),
+                ("b128_half_on_a", "--batch 128 default (last 128 rows as a row of half-tiles), same box, --steps 30"),
+                ("b128_half_off_b", "--batch 128 SEGCLIP_PQ_HALF=0, second pass"), ("b128_half_on_b", "--batch 128 default, second pass"),
+                ("full_fold_off_a", "--full-loss SEGCLIP_FOLD_GRADS=0 (the autograd engine adds the two passes' parameter gradients), same box"),
+                ("full_fold_on_a", "--full-loss default (config.fold_param_grads), same box"),
+                ("full_fold_off_b", "--full-loss SEGCLIP_FOLD_GRADS=0, second pass"), ("full_fold_on_b", "--full-loss default, second pass"),
                 ("wgrad_single_a", "SEGCLIP_WGRAD_GROUP=1 (one launch per weight gradient), same box, --steps 30"),
                 ("wgrad_grouped_a", "default (grouped weight gradients), same box, --steps 30"),
                 ("wgrad_single_b", "SEGCLIP_WGRAD_GROUP=1, second pass"), ("wgrad_grouped_b", "default, second pass")):
@@ -46,7 +55,7 @@ for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base o
         continue
     d = last_json(R + f"bench_{n}.json")
     cfg[n] = {"command": "python bench.py --no-cpu-baseline " + desc, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-              "config": d["config"], "roofline": d.get("roofline")}
+              "config": d["config"], "roofline": d.get("roofline"), "clocks": d.get("clocks")}
 json.dump(cfg, open(P + "bench_configs.json", "w"), indent=1)
 txt = ("# rocprofv3 --pmc passes (counters only; one counter group per run) on single GEMM shapes of the shipped 8-phase kernel\n"
        "# (tools/pmc_gemm.sh via tools/profile_round.sh); values per launch = mean of 3 launches of tools/one_gemm.py.\n"
@@ -86,7 +95,9 @@ for a, h in (("gemm_shapes.txt", "# GEMM rates per shape (tools/bench_gemm.py, H
              ("hbm_kernels.txt", "# HBM-bound kernels against 8 TB/s (tools/bench_hbm.py)\n"),
              ("attn.txt", "# attention kernels in isolation (tools/bench_attn.py): T=196 vision (single-pass backward), T=77 causal text\n"),
              ("center_stage.txt", "# Kernel time of the learnable-center stage alone (SemanticLearnerModule forward + backward, B = 256, bf16, t18 mode;\n# tools/debug/center_stage_profile.py, torch profiler, mean of 3 passes).  Round-3 build: 4.71 ms over 361 launches (DESIGN 4.5)\n"),
-             ("stream_gaps.txt", "# tools/stream_gaps.py on the kernel trace of the bench child (profiled run: the host is slower than in the timed run)\n")):
+             ("stream_gaps.txt", "# tools/stream_gaps.py on the kernel trace of the bench child (profiled run: the host is slower than in the timed run)\n"),
+             ("stream_breakdown.txt", "# tools/stream_breakdown.py on the same trace: kernel time per stream and kernel (the window holds more than the 3 passes it divides by:\n# read the rows relative to each other - stream 0 is the vision tower + everything serial, i.e. the critical path)\n"),
+             ("gemm_half_tile.txt", "# tools/bench_pq_half.py: gemm_bf16_pq.hip with full tiles only against the half-tile tail (SEGCLIP_PQ_HALF=2, per-call switch), interleaved rounds, M = 50432; outputs bit-identical\n")):
     if os.path.exists(R + a):
         open(P + a, "w").write(h + open(R + a).read())
 if os.path.exists(R + "eager_ab.json"):
