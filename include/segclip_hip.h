@@ -347,6 +347,9 @@ int segclip_masked_mse_bwd(const void* pred, const float* target, const float* m
                            int64_t B, int64_t T, int64_t Dp, int pred_dtype, void* stream);
 /* out[i] = x[i] * (*s)  (device scalar) ;  out[0] = scale * sum(x)  (deterministic single block) */
 int segclip_scale(const float* x, const float* s, float* out, int64_t n, void* stream);
+/* out = -log(-log(clamp(u, FLT_MIN, 1 - FLT_EPSILON))): Gumbel(0,1) noise of the hard assignment from uniform samples
+ * (reference modules/module_seg_vit.py:223-226, torch.distributions.Gumbel(0, 1).sample); u and out may alias */
+int segclip_gumbel_from_uniform(const float* u, float* out, int64_t n, void* stream);
 int segclip_reduce_sum(const float* x, float* out, int64_t n, float scale, void* stream);
 
 /* Evaluation tier: positional table at another grid, modules/module_clip_vtransformer.py:35-53 =

@@ -101,6 +101,7 @@ SIGNATURES = {
     "segclip_act_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, vp]),
     "segclip_add": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
     "segclip_scale": (C.c_int, [vp, vp, vp, i64, vp]),
+    "segclip_gumbel_from_uniform": (C.c_int, [vp, vp, i64, vp]),
     "segclip_reduce_sum": (C.c_int, [vp, vp, i64, f32, vp]),
     "segclip_ce_labels_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, i64, i64, vp]),
     "segclip_ce_labels_bwd": (C.c_int, [vp, vp, vp, i64, vp, vp, vp, i64, i64, vp]),

@@ -176,6 +176,10 @@ def gumbel(shape, device):
     if t is not None:
         return t
     u = torch.rand(shape, device=device, dtype=torch.float32)
+    if u.is_cuda:       # clamp / log / neg / log / neg as one kernel, in place (the draw itself stays torch's generator)
+        from . import _lib as L
+        L.check(L.load().segclip_gumbel_from_uniform(L.ptr(u), L.ptr(u), u.numel(), L.stream()), "gumbel_from_uniform")
+        return u
     tiny = torch.finfo(torch.float32).tiny
     u = u.clamp(min=tiny, max=1.0 - torch.finfo(torch.float32).eps)
     return -torch.log(-torch.log(u))

@@ -87,6 +87,15 @@ __global__ void scale_kernel(const float* x, const float* s, float* out, int64_t
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = x[i] * sc;
 }
+// Gumbel(0,1) from uniform samples: g = -log(-log(clamp(u, tiny, 1 - eps)))  (torch.distributions.Gumbel.sample as
+// config.gumbel wrote it op by op: clamp, log, neg, log, neg); logf is the same library routine ATen's log kernel calls
+__global__ void gumbel_from_uniform_kernel(const float* __restrict__ u, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = u[i];
+    v = v < 1.17549435e-38f ? 1.17549435e-38f : (v > 1.0f - 1.1920929e-07f ? 1.0f - 1.1920929e-07f : v);
+    out[i] = -logf(-logf(v));
+  }
+}
 // out[0] = scale * sum(x[0..n))   (single block, deterministic)
 __global__ void reduce_sum_kernel(const float* x, float* out, int64_t n, float scale) {
   __shared__ float red[16];
@@ -759,6 +768,12 @@ extern "C" int segclip_scatter_rows(const void* dout, const int64_t* idx, void* 
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(B * To * D)), dim3(TPB), 0, ST, dout, idx, dsrc, B, (int)Ts, (int)To,
                      (int)D, dt, 1);
   SEGCLIP_CHECK_LAUNCH("scatter_rows");
+  return 0;
+}
+extern "C" int segclip_gumbel_from_uniform(const float* u, float* out, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gumbel_from_uniform_kernel, dim3(grid1d(n)), dim3(TPB), 0, ST, u, out, n);
+  SEGCLIP_CHECK_LAUNCH("gumbel_from_uniform");
   return 0;
 }
 extern "C" int segclip_mean_cat_fwd(const float* x, float* out, int64_t B, int64_t T, int64_t D, void* stream) {

@@ -676,6 +676,26 @@ def test_mae_unshuffle(B, K, L, D):
         assert float(mt.grad.abs().max()) == 0.0
 
 
+def test_gumbel_noise_transform():
+    """config.gumbel: torch's uniform draw, then -log(-log(clamp(u))) as one kernel - the values of the op-by-op expression
+    (same generator state -> same noise as before), including the clamped end points."""
+    from segclip_amd import config
+    torch.manual_seed(5)
+    g = config.gumbel((7, 8, 196), torch.device(DEV))
+    torch.manual_seed(5)
+    u = torch.rand((7, 8, 196), device=DEV, dtype=torch.float32)
+    tiny, eps = torch.finfo(torch.float32).tiny, torch.finfo(torch.float32).eps
+    ref = -torch.log(-torch.log(u.clamp(min=tiny, max=1.0 - eps)))
+    close(g, ref, 2e-6, 2e-6, "gumbel transform")
+    from segclip_amd import _lib as L
+    e = torch.tensor([0.0, 1.0, 0.5, tiny, 1.0 - eps], device=DEV)
+    out = torch.empty_like(e)
+    L.check(L.load().segclip_gumbel_from_uniform(L.ptr(e), L.ptr(out), e.numel(), L.stream()), "gumbel")
+    refe = -torch.log(-torch.log(e.clamp(min=tiny, max=1.0 - eps)))
+    assert bool(torch.isfinite(out).all())
+    close(out, refe, 2e-6, 2e-6, "gumbel transform at the clamped ends")
+
+
 def test_mask_sort_bit_exact():
     B, Lq = 6, 197
     g = torch.Generator().manual_seed(3)
