@@ -695,7 +695,7 @@ int launch_fwd_pf(const FwdArgs& a, int nitems, hipStream_t stream) {
   if (per_cu == 0) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_pf_kernel<NT, CAUSAL, ABL>, (NT + 1) * 64, lds) != hipSuccess || n < 1) n = 1;
-    static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_GRID"); return e ? atoi(e) : 0; }();
+    static const int grid_env = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_FWD_GRID"); return e ? atoi(e) : 0; }();
     per_cu = grid_env > 0 ? grid_env : n;
   }
   const int cap = ncu_dev[dev] * per_cu;
@@ -734,9 +734,9 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     a.o_sb = d->o_sb; a.o_st = d->o_st; a.scale = d->scale; a.causal = d->causal;
     a.klen = (const int*)d->klen;
     // LDS-staged output rows: 117 -> 112 us at T = 196 (B = 256, H = 12), 27.8 -> 29.3 us at T = 77: on for the long sequences
-    static const int fwd_staged = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_STAGED"); return e ? atoi(e) : -1; }();
+    static const int fwd_staged = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_FWD_STAGED"); return e ? atoi(e) : -1; }();
     a.staged = fwd_staged >= 0 ? fwd_staged : (d->Tq > 128 ? 1 : 0);
-    static const int fwd_lean = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_LEAN"); return e ? atoi(e) : 1; }();
+    static const int fwd_lean = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_FWD_LEAN"); return e ? atoi(e) : 1; }();
     a.lean = fwd_lean;
     SEGCLIP_REQUIRE(!(d->klen && (d->flags & SEGCLIP_ATTN_FP8)), "attn_fwd: klen is not supported by the fp8 kernel");
     if (smallq::covers(d)) {   // at most 8 queries (the learnable-center cross-attention): one wave per (batch, head), VALU
@@ -749,7 +749,7 @@ extern "C" int segclip_attn_fwd(const segclip_attn_desc* d, void* stream_) {
     const int tiles = (int)cdiv(d->Tq, 32);
     // self-attention of 65..96 / 161..200 tokens: the persistent kernel with a loader wave (attention_pf.inc);
     // SEGCLIP_ATTN_FWD_PF=0 falls back to one workgroup per (batch, head)
-    static const int use_pf = [] { const char* e = getenv("SEGCLIP_ATTN_FWD_PF"); return e ? atoi(e) : 1; }();
+    static const int use_pf = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_FWD_PF"); return e ? atoi(e) : 1; }();
     if (use_pf && d->Tq == d->Tk && !(d->flags & SEGCLIP_ATTN_FP8) && (tiles == 3 || tiles == 6 || tiles == 7) &&
         fwd_pf_lds_bytes(tiles, (int)d->Tq) <= 160 * 1024) {
       const int nitems = (int)(d->B * d->H);
@@ -865,7 +865,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     const int tiles = (int)cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32);
     // self-attention: the single-pass kernel (attention_sp.inc), one wave per key tile.  SEGCLIP_ATTN_BWD_SP=0 falls back
     // to the two-pass kernel (benchmarking); cross-attention (Tq != Tk) always takes the two-pass kernel.
-    static const int use_sp = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_SP"); return e ? atoi(e) : 1; }();
+    static const int use_sp = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_SP"); return e ? atoi(e) : 1; }();
     if (use_sp && d->Tq == d->Tk) {
       const size_t lds_sp = bwd_sp_lds_bytes(tiles * 32);
       // per DEVICE (function attributes and the CU count belong to the device the launch goes to, not to the process)
@@ -890,7 +890,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
         ncu_dev[dev] = n;
       }
       const int ncu = ncu_dev[dev];
-      static const int grid_env = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_GRID"); return e ? atoi(e) : -1; }();
+      static const int grid_env = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_GRID"); return e ? atoi(e) : -1; }();
       int per_cu = 0;
       hipError_t eo = masked ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_sp_bf16_kernel<true>, tiles * 64, lds_sp)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_sp_bf16_kernel<false>, tiles * 64, lds_sp);
@@ -901,7 +901,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
       // vision tower (no mask, 5-7 tiles): the variant whose memory traffic is issued by a loader wave (attention_spl.inc);
       // SEGCLIP_ATTN_BWD_SPL=0 keeps attention_sp.inc
       // attention_sq.inc: the query tiles as a stream (round 5; SEGCLIP_ATTN_BWD_SQ=1)
-      static const int use_sq = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_SQ"); return e ? atoi(e) : 0; }();
+      static const int use_sq = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_SQ"); return e ? atoi(e) : 0; }();
       if (use_sq && !masked && tiles >= 5 && tiles <= 7 && bwd_sq_lds_bytes((int)d->Tq) <= 160 * 1024) {
         static bool sq_attr_set[64] = {};
         if (!sq_attr_set[dev]) {
@@ -916,7 +916,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
         SEGCLIP_CHECK_LAUNCH("attn_bwd_sq_bf16");
         return 0;
       }
-      static const int use_spl = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_SPL"); return e ? atoi(e) : 1; }();
+      static const int use_spl = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_SPL"); return e ? atoi(e) : 1; }();
       if (use_spl && !masked && tiles >= 5 && tiles <= 7 && bwd_spl_lds_bytes((int)d->Tq) <= 160 * 1024) {
         static bool spl_attr_set[64] = {};
         if (!spl_attr_set[dev]) {
@@ -941,7 +941,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     // 4 waves per workgroup (each wave walks over 1-2 tiles): two such workgroups fit the registers (2 waves per SIMD
     // at ~215 VGPRs) and the LDS of a CU, so their load / MFMA / store phases interleave.  SEGCLIP_ATTN_BWD_WAVES
     // overrides (benchmarking).
-    static const int force_waves = [] { const char* e = getenv("SEGCLIP_ATTN_BWD_WAVES"); return e ? atoi(e) : 0; }();
+    static const int force_waves = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_WAVES"); return e ? atoi(e) : 0; }();
     int nw = tiles < 4 ? tiles : 4;
     if (force_waves >= 1 && force_waves <= 8) nw = tiles < force_waves ? tiles : force_waves;
     const int tp = (int)(cdiv(d->Tq > d->Tk ? d->Tq : d->Tk, 32) * 32);

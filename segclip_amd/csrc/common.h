@@ -1,5 +1,7 @@
 // Shared device/host helpers for the SegCLIP gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -109,9 +111,21 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Timing ablations that produce GARBAGE results (SEGCLIP_ATTN_ABL, SEGCLIP_P8_EPI_ABL, SEGCLIP_P8_ABL, SEGCLIP_PQ_ABL) exist only in
 // libraries built with `build.sh -DSEGCLIP_EXPERIMENTS`; a production build ignores those environment variables.
 #include <stdlib.h>
+// Kernel-selection / tuning switches of the library (SEGCLIP_GEMM_PQ, SEGCLIP_PQ_HALF, SEGCLIP_ATTN_FWD_PF, ...: A/B tools and
+// profile scripts).  They are honoured only when SEGCLIP_TUNING=1 is set as well: a production process cannot have its kernels
+// re-routed by a stray variable, and one that tries is told so once per variable.
+static inline const char* segclip_tuning_env(const char* name) {
+  static const bool on = [] { const char* t = getenv("SEGCLIP_TUNING"); return t != nullptr && atoi(t) != 0; }();
+  const char* e = getenv(name);
+  if (e != nullptr && !on) {
+    fprintf(stderr, "segclip_hip: %s=%s ignored (tuning switches need SEGCLIP_TUNING=1)\n", name, e);
+    return nullptr;
+  }
+  return e;
+}
 static inline int segclip_ablation_env(const char* name) {
 #ifdef SEGCLIP_EXPERIMENTS
-  const char* e = getenv(name);
+  const char* e = segclip_tuning_env(name);
   return e ? atoi(e) : 0;
 #else
   (void)name;

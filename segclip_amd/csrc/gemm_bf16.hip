@@ -389,7 +389,7 @@ static int choose_splits(const segclip_gemm_desc* d) {
   if (d->bias || d->residual || d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact) return 1;
   const int64_t nb = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
   const int64_t ksteps = cdiv(d->K, BK);
-  static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  static const int force_tile = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (want_dma(d) && force_tile == 128) {
     // 128x128 tiles, two workgroups per CU: one round = 512 workgroups
     const int64_t tiles = cdiv(d->M, 128) * cdiv(d->N, 128) * nb;
@@ -468,9 +468,9 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   g.touch = 0;
   g.abl = 0;
   g.colgroups = 1;
-  static const int xw_epi = [] { const char* e = getenv("SEGCLIP_EPI_XW"); return e ? atoi(e) : 2; }();
+  static const int xw_epi = [] { const char* e = segclip_tuning_env("SEGCLIP_EPI_XW"); return e ? atoi(e) : 2; }();
   g.xw_epi = xw_epi;
-  static const int slab_staged = [] { const char* e = getenv("SEGCLIP_P8_SLAB_STAGED"); return e ? atoi(e) : 1; }();
+  static const int slab_staged = [] { const char* e = segclip_tuning_env("SEGCLIP_P8_SLAB_STAGED"); return e ? atoi(e) : 1; }();
   g.slab_staged = slab_staged;
   g.colsum_part = nullptr;
   dim3 grid((unsigned)(g.nbx * g.nby), (unsigned)g.splits, (unsigned)nb);
@@ -491,7 +491,7 @@ int segclip_gemm_bf16_launch(const segclip_gemm_desc* d, hipStream_t stream) {
       return SEGCLIP_ERR_UNSUPPORTED;
     }
   } else if (want_dma(d)) {
-    static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    static const int force_tile = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
     // 256x256 tiles: the phase-pipelined kernel (gemm_bf16_p8.hip); 256x128 / 128x128 tiles: the one-barrier-per-K-tile
     // kernel (gemm_bf16_dma.hip)
     // 256x256 tiles, bf16 output, full tiles, no split-K: the persistent kernel with the overlapped output path

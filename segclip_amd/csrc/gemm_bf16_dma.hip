@@ -329,12 +329,12 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
   // Round 4: problems whose 256-row tiles cannot fill the 256 CUs (the center stage's q-side linears: M = 8 B = 2048 rows,
   // 48-192 tiles) take the 128x128 tile: four times the workgroups, two per CU, half the K-loop time per tile
   // (SEGCLIP_GEMM_SMALL_TILES=0 switches the rule off; a forward + backward pass of the center stage: see DESIGN 4.4).
-  static const int small_rule = [] { const char* e = getenv("SEGCLIP_GEMM_SMALL_TILES"); return e ? atoi(e) : 1; }();
+  static const int small_rule = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_SMALL_TILES"); return e ? atoi(e) : 1; }();
   const int bn_big = pick_bn(d, nb * splits);
   const bool auto_small = small_rule && d->M >= 128 && d->N >= 128 && !(d->aux_kind == 2 && d->aux) && !g.colsum_part &&
                           cdiv(d->M, 256) * cdiv(d->N, bn_big) * nb * splits < 256;
 #ifdef SEGCLIP_GEMM_EXPERIMENTS  // build.sh -DSEGCLIP_GEMM_EXPERIMENTS: the 3-stage-ring instances (+ hipcc time)
-  static const int force_tile = [] { const char* e = getenv("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  static const int force_tile = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const bool small = force_tile == 128 || (force_tile == 0 && auto_small);
   const bool three = force_tile == 3;  // experiment: 256x128 tiles with a 3-stage ring (96 KiB in flight)
 #else

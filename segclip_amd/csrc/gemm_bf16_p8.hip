@@ -526,7 +526,7 @@ void segclip_p8_launch_abl4(dim3, hipStream_t, const void*);
 // returns false when the shape does not meet this kernel's preconditions.
 bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t kper, int64_t nb,
                               hipStream_t stream) {
-  static const int disabled = [] { const char* e = getenv("SEGCLIP_GEMM_P8"); return e ? atoi(e) == 0 : 0; }();
+  static const int disabled = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_P8"); return e ? atoi(e) == 0 : 0; }();
   if (disabled) return false;
   Args g = *reinterpret_cast<const Args*>(args_);
   const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
@@ -538,8 +538,8 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   // 32-bit DMA offsets: 256 rows (or 64 k-rows) of the leading dimension must stay below 4 GiB
   if ((a_ks ? 64 : 256) * (a_ks ? d->sak : d->sam) * 2 >= (int64_t)1 << 31) return false;
   if ((b_ks ? 64 : 256) * (b_ks ? d->sbk : d->sbn) * 2 >= (int64_t)1 << 31) return false;
-  static const int touch = [] { const char* e = getenv("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
-  static const int stagger = [] { const char* e = getenv("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 2000; }();   // unit cap in cycles; 0 = off.  In the step (two runs each): 5000: 43.74 ms, 2000: 43.50, 1000: 43.47, 0: 43.47, 12000: 43.98
+  static const int touch = [] { const char* e = segclip_tuning_env("SEGCLIP_P8_TOUCH"); return e ? atoi(e) : 0; }();   // measured slower (see the kernel)
+  static const int stagger = [] { const char* e = segclip_tuning_env("SEGCLIP_P8_STAGGER"); return e ? atoi(e) : 2000; }();   // unit cap in cycles; 0 = off.  In the step (two runs each): 5000: 43.74 ms, 2000: 43.50, 1000: 43.47, 0: 43.47, 12000: 43.98
   static const int epi_abl = segclip_ablation_env("SEGCLIP_P8_EPI_ABL");
   g.abl = epi_abl;
   g.touch = (touch ? 1 : 0) | (stagger > 0 ? 0 : 2) | (stagger << 2);   // bit 0: side-tile touch experiment, bit 1: no first-round stagger
@@ -548,7 +548,7 @@ bool segclip_gemm_bf16_p8_try(const segclip_gemm_desc* d, const void* args_, int
   // column groups of the tile order (experiment, SEGCLIP_P8_COLGROUPS = 2..4; default 1 = row-major): measured at
   // M = 50176 (tools/bench_epi.py): within +-3 % of row-major on every shape (N = 3072: -4 % with 3 groups; N = 768 with
   // 3 groups loses the A sharing: +18 %) - the weight refetch model in the kernel comment is not what bounds the K loop
-  static const int cg_env = [] { const char* e = getenv("SEGCLIP_P8_COLGROUPS"); return e ? atoi(e) : 0; }();
+  static const int cg_env = [] { const char* e = segclip_tuning_env("SEGCLIP_P8_COLGROUPS"); return e ? atoi(e) : 0; }();
   g.colgroups = splits > 1 ? 1 : (cg_env > 0 ? cg_env : 1);
   if (g.colgroups > g.nbx) g.colgroups = g.nbx;
   g.splits = splits;

@@ -974,8 +974,8 @@ void segclip_pq_launch_group(dim3 grid, hipStream_t stream, const void* args, co
 // the XCD's L2 writes back every dirty output line) per arriving workgroup and an acquire (buffer_inv sc1) in the last one,
 // whose 2 x 256 KiB of partials then arrive at one CU's load rate.  OFF by default (SEGCLIP_PQ_TAIL=2..4 enables it for A/B).
 static int pq_tail_plan(int64_t ntiles, int64_t nkt, int* r_out) {
-  static const int env = [] { const char* e = getenv("SEGCLIP_PQ_TAIL"); return e ? atoi(e) : 0; }();
-  static const int min_nkt = [] { const char* e = getenv("SEGCLIP_PQ_TAIL_MINK"); return e ? atoi(e) : 24; }();
+  static const int env = [] { const char* e = segclip_tuning_env("SEGCLIP_PQ_TAIL"); return e ? atoi(e) : 0; }();
+  static const int min_nkt = [] { const char* e = segclip_tuning_env("SEGCLIP_PQ_TAIL_MINK"); return e ? atoi(e) : 24; }();
   *r_out = 0;
   if (!env || ntiles <= 256) return 0;
   const int r = (int)(ntiles % 256);
@@ -992,8 +992,8 @@ static int pq_tail_plan(int64_t ntiles, int64_t nkt, int* r_out) {
 // then costs a half-tile's time (about 0.6 of a tile's: 3 of 4 operand units per K-tile, half the MFMAs, half the output).
 // No exchange between workgroups, results bit-identical to the full tiles'.  SEGCLIP_PQ_HALF=0 switches it off (A/B).
 static bool pq_half_on() {
-  static const int env = [] { const char* e = getenv("SEGCLIP_PQ_HALF"); return e ? atoi(e) : 1; }();
-  return (env == 2 ? [] { const char* e = getenv("SEGCLIP_PQ_HALF_NOW"); return e ? atoi(e) : 1; }() : env) != 0;
+  static const int env = [] { const char* e = segclip_tuning_env("SEGCLIP_PQ_HALF"); return e ? atoi(e) : 1; }();
+  return (env == 2 ? [] { const char* e = segclip_tuning_env("SEGCLIP_PQ_HALF_NOW"); return e ? atoi(e) : 1; }() : env) != 0;
 }
 static int pq_half_plan(int64_t ntiles) {
   if (!pq_half_on() || ntiles <= 256) return 0;
@@ -1041,9 +1041,9 @@ void segclip_pq_launch_w(int, dim3, hipStream_t, const void*);
 // Launch this kernel when the problem meets its preconditions (see the top of the file); false = not taken.
 bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int splits, int64_t nb, hipStream_t stream) {
   // SEGCLIP_GEMM_PQ: 1 (default) on, 0 off, 2 = consult SEGCLIP_GEMM_PQ_NOW (0/1) at every call (A/B tests in one process)
-  static const int mode_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ"); return e ? atoi(e) : 1; }();
+  static const int mode_env = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_PQ"); return e ? atoi(e) : 1; }();
   if (mode_env == 0) return false;
-  if (mode_env == 2) { const char* e = getenv("SEGCLIP_GEMM_PQ_NOW"); if (e && atoi(e) == 0) return false; }
+  if (mode_env == 2) { const char* e = segclip_tuning_env("SEGCLIP_GEMM_PQ_NOW"); if (e && atoi(e) == 0) return false; }
   const Args& a = *reinterpret_cast<const Args*>(args_);
   const bool a_ks = d->sak != 1, b_ks = d->sbk != 1;
   if (nb != 1 || d->a_dtype != SEGCLIP_BF16 || d->b_dtype != SEGCLIP_BF16) return false;
@@ -1051,7 +1051,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   // row of half-tiles (forward / data-gradient layouts; the weight gradient's M is a weight dimension)
   if (d->M % (a_ks ? BT : 128) != 0 || d->M < 128 || d->N % BT != 0 || d->K % BK != 0 || d->K < BK) return false;
   if (a_ks) {   // weight gradient: C(m,n) = sum_k A[k][m] B[k][n], fp32 out (split-K: raw partial tiles into the slabs)
-    static const int wg_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ_WGRAD"); return e ? atoi(e) : 1; }();
+    static const int wg_env = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_PQ_WGRAD"); return e ? atoi(e) : 1; }();
     if (!wg_env || !b_ks || d->c_dtype != SEGCLIP_F32) return false;
     if (d->bias || d->residual || d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact || a.colsum_part) return false;
     if (splits == 1 && (d->alpha != 1.0f || d->ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(d->C) & 15) != 0)) return false;
@@ -1073,7 +1073,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   if (splits != 1) return false;
   if (d->res_row_mod > 0 && !(d->c_dtype == SEGCLIP_F32 && d->residual != nullptr && d->r_dtype == SEGCLIP_F32)) return false;
   if (d->c_dtype == SEGCLIP_F32) {   // forward + fp32 residual -> fp32 (the fp32 residual stream): fp32 patches, fp32 row pass
-    static const int r32_env = [] { const char* e = getenv("SEGCLIP_GEMM_PQ_RES32"); return e ? atoi(e) : 1; }();
+    static const int r32_env = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_PQ_RES32"); return e ? atoi(e) : 1; }();
     if (!r32_env || b_ks || d->residual == nullptr || d->r_dtype != SEGCLIP_F32 || d->alpha != 1.0f) return false;
     if (d->aux || d->act != SEGCLIP_ACT_NONE || d->mul_dact || a.colsum_part) return false;
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

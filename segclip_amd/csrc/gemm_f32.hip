@@ -182,7 +182,7 @@ int segclip_gemm_f32_launch(const segclip_gemm_desc* d, hipStream_t stream) {
   // M <= 32: 32 x 128 tiles.  Otherwise, with fewer than half a chip of 128 x 128 tiles: 64 x 64 tiles (4x the workgroups),
   // K-step 64.  256 x 256 x 512: 94 -> 39 us (K-step 128: 47 us - the time is the LDS staging and the one-accumulator MFMA
   // chain of a wave, not the round trips)
-  static const int force_small = [] { const char* e = getenv("SEGCLIP_GEMM_F32_SMALL"); return e ? atoi(e) : -1; }();
+  static const int force_small = [] { const char* e = segclip_tuning_env("SEGCLIP_GEMM_F32_SMALL"); return e ? atoi(e) : -1; }();
   const bool skinny = force_small != 0 && d->M <= 32;
   const bool small = !skinny && (force_small >= 0 ? force_small != 0 : cdiv(d->N, 128) * cdiv(d->M, 128) * nb < 128);
   const int64_t bm = skinny ? 32 : (small ? 64 : 128), bn = skinny ? 128 : (small ? 64 : 128);

@@ -139,7 +139,7 @@ extern "C" int segclip_group_linear64(const void* const* in, const int64_t* ld_i
       a.W[i][o] = (const bf16_t*)p;
     }
   a.M = M; a.groups = groups;
-  static const int gsplit_env = [] { const char* e = getenv("SEGCLIP_GL64_GSPLIT"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : v; }();
+  static const int gsplit_env = [] { const char* e = segclip_tuning_env("SEGCLIP_GL64_GSPLIT"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : v; }();
   const int gsplit = gsplit_env < groups ? gsplit_env : groups;
   const dim3 grid((unsigned)cdiv(M, GL_WAVES * GL_ROWS), (unsigned)gsplit), block(GL_WAVES * 64);
   if (n_in == 1 && n_out == 1) hipLaunchKernelGGL((group_linear_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, a);

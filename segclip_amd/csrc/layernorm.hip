@@ -381,7 +381,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_multi_kernel(const float* _
 
 // 3 workgroups of 4 waves per CU (the pipelined kernel holds two rows per wave: ~130 VGPRs at 768 columns)
 int ln_blocks(int64_t rows) {
-  static const int cap = [] { const char* e = getenv("SEGCLIP_LN_BLOCKS"); const int v = e ? atoi(e) : 768; return v < 1 ? 1 : v; }();
+  static const int cap = [] { const char* e = segclip_tuning_env("SEGCLIP_LN_BLOCKS"); const int v = e ? atoi(e) : 768; return v < 1 ? 1 : v; }();
   int64_t b = cdiv(rows, WAVES);
   return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
 }

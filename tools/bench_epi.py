@@ -2,6 +2,7 @@
 numerical check of every variant against a torch fp32 product (random data, HIP events).
 SEGCLIP_P8_TOUCH=0/1 switches the side-tile touch of the 8-phase kernel (read once per process)."""
 import os, sys
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from segclip_amd import ops

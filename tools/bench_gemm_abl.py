@@ -1,5 +1,6 @@
 """Ablation timing of the phase-pipelined GEMM (set SEGCLIP_P8_ABL before starting): forward layout, two shapes."""
 import sys, os
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from segclip_amd import ops

@@ -2,6 +2,7 @@
 8-phase kernel gemm_bf16_p8.hip in ONE process: bit-exact comparison of the outputs (same products, same k order, same
 rounding) and interleaved timing rounds (SEGCLIP_GEMM_PQ=2 makes the dispatcher consult SEGCLIP_GEMM_PQ_NOW at every call)."""
 import os, sys
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 os.environ["SEGCLIP_GEMM_PQ"] = "2"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

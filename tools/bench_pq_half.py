@@ -2,6 +2,7 @@
 against the same kernel without it, in ONE process: SEGCLIP_PQ_HALF=2 makes the dispatcher consult SEGCLIP_PQ_HALF_NOW at
 every call.  Outputs must be bit-identical (same products, same k order, same rounding); timing in interleaved rounds."""
 import os, sys
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 os.environ["SEGCLIP_PQ_HALF"] = "2"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

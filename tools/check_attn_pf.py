@@ -32,7 +32,7 @@ if __name__ == "__main__":
         res = []
         for pf in ("0", "1"):
             p = os.path.join(td, f"pf{pf}.pt")
-            subprocess.run([sys.executable, __file__, p], check=True, env=dict(os.environ, SEGCLIP_ATTN_FWD_PF=pf))
+            subprocess.run([sys.executable, __file__, p], check=True, env=dict(os.environ, SEGCLIP_TUNING="1", SEGCLIP_ATTN_FWD_PF=pf))
             res.append(torch.load(p))
         bad = 0
         for k in res[0]:

@@ -2,6 +2,7 @@
 (SEGCLIP_ATTN_BWD_SQ=0) and against an fp32 torch reference, same inputs: runs itself twice (the switch is read once per
 process) and compares dQ | dK | dV and the per-sample token sums.  Also prints the kernel time of each variant."""
 import math, os, subprocess, sys, tempfile
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # B, T, H, hd
 CASES = [(256, 196, 12, 64), (5, 197, 8, 64), (3, 224, 2, 64), (300, 196, 12, 64), (2, 161, 3, 64), (700, 170, 5, 64), (4, 196, 3, 48)]
@@ -46,7 +47,7 @@ if __name__ == "__main__":
         res = []
         for sq in ("0", "1"):
             p = os.path.join(td, f"sq{sq}.pt")
-            subprocess.run([sys.executable, __file__, p], check=True, env=dict(os.environ, SEGCLIP_ATTN_BWD_SQ=sq))
+            subprocess.run([sys.executable, __file__, p], check=True, env=dict(os.environ, SEGCLIP_TUNING="1", SEGCLIP_ATTN_BWD_SQ=sq))
             res.append(torch.load(p))
         bad = 0
         for k in sorted(res[0]):

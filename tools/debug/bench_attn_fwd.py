@@ -1,4 +1,5 @@
 import sys, os, math
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.getcwd())
 import torch
 from segclip_amd import ops

@@ -1,5 +1,6 @@
 """Run with SEGCLIP_P8_EPI_ABL=0/2/3/4/5: operand rows from a cache-resident window (results wrong for != 0)."""
 import sys, os
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from segclip_amd import ops

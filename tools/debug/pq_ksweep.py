@@ -1,5 +1,6 @@
 """K sweep of the persistent GEMM (intercept = per-tile fixed cost, slope = time per K-tile) and output-path ablations."""
 import os, sys
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 os.environ["SEGCLIP_GEMM_PQ"] = "2"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

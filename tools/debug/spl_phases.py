@@ -1,5 +1,6 @@
 """Phase times (s_memtime) of the loader-wave attention backward; experiments build, SEGCLIP_ATTN_ABL=9."""
 import sys, os, math
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.getcwd())
 os.environ["SEGCLIP_ATTN_ABL"] = "9"
 import torch

@@ -1,6 +1,7 @@
 """Phase times (s_memtime) of the streaming attention backward (attention_sq.inc); experiments build,
 SEGCLIP_ATTN_ABL=9 SEGCLIP_ATTN_BWD_SQ=1."""
 import sys, os, math
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.getcwd())
 os.environ["SEGCLIP_ATTN_ABL"] = "9"
 os.environ["SEGCLIP_ATTN_BWD_SQ"] = "1"

@@ -1,5 +1,6 @@
 """Where the streaming backward differs from an fp32 reference: section (dQ|dK|dV), sample, token, head."""
 import sys, os, math
+os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.getcwd())
 os.environ["SEGCLIP_ATTN_BWD_SQ"] = "1"
 import torch

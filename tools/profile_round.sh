@@ -26,12 +26,13 @@ b vitl14 --no-cpu-baseline --no-traffic --no-parity-leg --spec vitl14_336 --batc
 b text_trim --no-cpu-baseline --no-roofline --no-parity-leg --text-trim
 for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --no-parity-leg --batch $bsz; done
 # same-box A/B of the grouped weight gradients (config.wgrad_group_blocks): one launch per gradient vs the default, twice
+# (library kernel-selection switches need SEGCLIP_TUNING=1)
 # same-box A/Bs, twice each: the half-tile tail of gemm_bf16_pq.hip (SEGCLIP_PQ_HALF=0 = full tiles only), B = 256 and B = 128
 # (at B = 128 the switch also decides whether M = 256 q + 128 runs on that kernel at all); gradient folding on the full loss
 for rep in a b; do
-  SEGCLIP_PQ_HALF=0 b half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
+  SEGCLIP_TUNING=1 SEGCLIP_PQ_HALF=0 b half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
   b half_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
-  SEGCLIP_PQ_HALF=0 b b128_half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
+  SEGCLIP_TUNING=1 SEGCLIP_PQ_HALF=0 b b128_half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
   b b128_half_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
   SEGCLIP_FOLD_GRADS=0 b full_fold_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
   b full_fold_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
