@@ -447,6 +447,13 @@ int segclip_segmean_fwd(const uint8_t* idx, const void* v, int v_dtype, const fl
 int segclip_segmean_bwd(const float* dout, const float* out, const uint8_t* idx, const void* v, int v_dtype, const float* counts,
                         void* dv, float* dhard, int64_t B, int64_t G, int64_t T, int64_t D, void* stream);
 
+/* Token rows from the centers (MAE branch, reference modules/module_seg_vit.py:338-342): out (B,M,D) = a (B,M,G) @ x (B,G,D), fp32,
+ * and the backward da (B,M,G) = dout x^T, dx (B,G,D) = a^T dout.  Covers G = 8, D a multiple of 4 up to 4096; other shapes return
+ * SEGCLIP_ERR_UNSUPPORTED (use segclip_gemm). */
+int segclip_recon_mix_fwd(const float* a, const float* x, float* out, int64_t B, int64_t M, int64_t G, int64_t D, void* stream);
+int segclip_recon_mix_bwd(const float* a, const float* x, const float* dout, float* da, float* dx, int64_t B, int64_t M, int64_t G,
+                          int64_t D, void* stream);
+
 /* Assignment logits of the center stage: attn[b][g][t] = q[b][g][:] . k[b][t][:] (fp32, un-scaled; reference
  * modules/module_seg_vit.py:304) and the backward dq = dl k, dk = dl^T q.  Covers G = 8, D = 768 | 1024; other shapes return
  * SEGCLIP_ERR_UNSUPPORTED (use segclip_gemm).  Not the summation order of the exact-fp32 GEMM. */

@@ -110,6 +110,8 @@ SIGNATURES = {
     "segclip_vis_assemble": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_embed_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "segclip_embed_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_recon_mix_fwd": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "segclip_recon_mix_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "segclip_mean_cat_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp]),
     "segclip_mean_cat_bwd": (C.c_int, [vp, vp, i64, i64, i64, vp]),
     "segclip_mae_unshuffle_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),

@@ -165,6 +165,68 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
 }
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
+// Reconstruction of the token rows from the centers (MAE branch, reference modules/module_seg_vit.py:338-342):
+// out[b][m][:] = sum_g a[b][m][g] * x[b][g][:], G = 8, fp32.  As a batched GEMM with K = 8 this ran on the exact-fp32 MFMA kernel at
+// 0.8 ms per call; it is 8 FMAs per output element and one pass over the output.  One wave per (sample, 256-column chunk,
+// token range): the sample's 8 center rows stay in registers, a[b][m][0..7] is wave-uniform (scalar loads).
+__global__ __launch_bounds__(64) void recon_mix_fwd_kernel(const float* __restrict__ a, const float* __restrict__ x, float* __restrict__ out,
+                                                           int M, int D4, int chunks, int mseg) {
+  const int b = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + threadIdx.x;
+  if (c >= D4) return;
+  f32x4 xg[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) xg[g] = reinterpret_cast<const f32x4*>(x)[((int64_t)b * CG + g) * D4 + c];
+  const int m0 = blockIdx.y * mseg, m1 = m0 + mseg < M ? m0 + mseg : M;
+  const float* ab = a + ((int64_t)b * M + m0) * CG;
+  f32x4* ob = reinterpret_cast<f32x4*>(out) + ((int64_t)b * M + m0) * D4 + c;
+  for (int m = m0; m < m1; ++m, ab += CG, ob += D4) {
+    f32x4 acc = xg[0] * ab[0];
+#pragma unroll
+    for (int g = 1; g < CG; ++g) acc += xg[g] * ab[g];
+    *ob = acc;
+  }
+}
+// backward: dx[b][g][:] = sum_m a[b][m][g] * dout[b][m][:]  and  da[b][m][g] = dout[b][m][:] . x[b][g][:].  One workgroup per
+// sample, one lane per 4 columns (D / 4 lanes, whole waves): the token loop carries the dx accumulators; the 8 dot products of a
+// token are reduced inside each wave (wave_sum8) and across the waves through a double-buffered LDS array (one barrier per token).
+__global__ __launch_bounds__(1024) void recon_mix_bwd_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                             const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ dx,
+                                                             int M, int D4) {
+  __shared__ float red[2][16][CG];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+  const bool live = t < D4;
+  f32x4 xg[CG], acc[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    xg[g] = live ? reinterpret_cast<const f32x4*>(x)[((int64_t)b * CG + g) * D4 + t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* ab = a + (int64_t)b * M * CG;
+  const f32x4* gb = reinterpret_cast<const f32x4*>(dout) + (int64_t)b * M * D4 + t;
+  float* dab = da + (int64_t)b * M * CG;
+  for (int m = 0; m < M; ++m) {
+    const f32x4 g4 = live ? gb[(int64_t)m * D4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    float pd[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+      acc[g] += g4 * ab[m * CG + g];
+      pd[g] = dot4(g4, xg[g]);
+    }
+    const float s = wave_sum8(pd, lane);          // lane holds the wave's total of value lane >> 3
+    if ((lane & 7) == 0) red[m & 1][wave][lane >> 3] = s;
+    __syncthreads();
+    if (t < CG) {
+      float v = red[m & 1][0][t];
+      for (int w = 1; w < nw; ++w) v += red[m & 1][w][t];
+      dab[m * CG + t] = v;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int g = 0; g < CG; ++g) reinterpret_cast<f32x4*>(dx)[((int64_t)b * CG + g) * D4 + t] = acc[g];
+  }
+}
+
 // assignment logits attn[b][g][t] = q[b][g][:] . k[b][t][:]  (reference modules/module_seg_vit.py:304, un-scaled), fp32
 template <int NCG>
 __global__ __launch_bounds__(256) void center_logits_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -445,6 +507,32 @@ extern "C" int segclip_segmean_bwd(const float* dout, const float* out, const ui
   return 0;
 }
 
+// out (B,M,D) = a (B,M,8) @ x (B,8,D), fp32, and its backward (reference modules/module_seg_vit.py:342: the MAE branch's
+// ReconstructLayer).  G = 8 and D a multiple of 4, at most 4096 columns; else SEGCLIP_ERR_UNSUPPORTED (the caller uses segclip_gemm).
+extern "C" int segclip_recon_mix_fwd(const float* a, const float* x, float* out, int64_t B, int64_t M, int64_t G, int64_t D, void* stream) {
+  if (G != CG || D % 4 != 0 || D > 4096 || D < 4) {
+    segclip_set_error("recon_mix: G=%lld, D=%lld not covered", (long long)G, (long long)D);
+    return SEGCLIP_ERR_UNSUPPORTED;
+  }
+  if (B * M == 0) return 0;
+  const int D4 = (int)(D / 4), chunks = (D4 + 63) / 64;
+  const int nseg = (int)(M >= 64 ? 4 : 1), mseg = (int)((M + nseg - 1) / nseg);
+  hipLaunchKernelGGL(recon_mix_fwd_kernel, dim3((unsigned)(B * chunks), (unsigned)nseg), dim3(64), 0, ST, a, x, out, (int)M, D4, chunks, mseg);
+  SEGCLIP_CHECK_LAUNCH("recon_mix_fwd");
+  return 0;
+}
+extern "C" int segclip_recon_mix_bwd(const float* a, const float* x, const float* dout, float* da, float* dx, int64_t B, int64_t M,
+                                     int64_t G, int64_t D, void* stream) {
+  if (G != CG || D % 4 != 0 || D > 4096 || D < 4) {
+    segclip_set_error("recon_mix: G=%lld, D=%lld not covered", (long long)G, (long long)D);
+    return SEGCLIP_ERR_UNSUPPORTED;
+  }
+  if (B == 0) return 0;
+  const int D4 = (int)(D / 4), threads = ((D4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(recon_mix_bwd_kernel, dim3((unsigned)B), dim3((unsigned)threads), 0, ST, a, x, dout, da, dx, (int)M, D4);
+  SEGCLIP_CHECK_LAUNCH("recon_mix_bwd");
+  return 0;
+}
 // Assignment logits of the center stage, attn[b][g][t] = q[b][g][:] . k[b][t][:] (fp32; reference modules/module_seg_vit.py:304),
 // and their backward dq = dl k, dk = dl^T q, as per-sample token loops.  G = 8, D = 768 or 1024 (else SEGCLIP_ERR_UNSUPPORTED:
 // the caller uses segclip_gemm).  The summation order over D differs from the exact-fp32 GEMM's: used in bf16 mode only.

@@ -371,7 +371,23 @@ __global__ __launch_bounds__(64) void mae_unshuffle_bwd_kernel(const float* __re
   const int j = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + threadIdx.x;
   if (c >= D4) return;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t b = 0; b < B; ++b) {
+  int64_t b = 0;
+  for (; b + 8 <= B; b += 8) {          // eight samples' loads in flight (the walk is latency-bound); the sums keep sample order
+    f32x4 g[8];
+    int64_t id[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      g[u] = reinterpret_cast<const f32x4*>(dout)[((b + u) * L + j) * D4 + c];
+      id[u] = ids[(b + u) * L + j];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s += g[u];
+      if (id[u] < K) reinterpret_cast<f32x4*>(dx)[((b + u) * K + (id[u] < 0 ? 0 : id[u])) * D4 + c] = g[u];
+      else m += g[u];
+    }
+  }
+  for (; b < B; ++b) {
     const f32x4 g = reinterpret_cast<const f32x4*>(dout)[(b * L + j) * D4 + c];
     const int64_t id = ids[b * L + j];
     s += g;

@@ -302,7 +302,7 @@ class ReconstructLayer(nn.Module):
         # Linear(8,8) over the center axis: K = 8 is below the MFMA K granule -> exact f32 path always
         a = ops.linear(attn.permute(0, 2, 1).contiguous().float(), self.rec_proj_a.a_fc.weight,
                        self.rec_proj_a.a_fc.bias, act_dtype=torch.float32)          # (B,M,G)
-        out = ops.bmm(a, inputs.float(), transB=False, out_dtype=torch.float32)      # (B,M,D)
+        out = ops.recon_mix(a, inputs.float())                                       # (B,M,D) = a @ inputs, K = 8
         return ops.ActFn.apply(out, ops.ACT_QUICK_GELU)
 
 

@@ -398,6 +398,17 @@ def p_wgrad(dy, x, w_kn=False, out=None, defer=None):
     if x.dtype == torch.float32 and dy.dtype != torch.float32:
         x = p_cast(x, dy.dtype)  # only the A operand may be fp32 on the bf16 path
     dw = out if out is not None else _empty((N, K), torch.float32, dy)
+    if (dy.dtype == torch.float32 and x.dtype == torch.float32 and N * K <= 1024 and M >= 4096 and M % 64 == 0
+            and dw.is_contiguous()):
+        # a tiny weight (the 8 x 8 Linear over the center axis of the MAE branch's ReconstructLayer, reference
+        # modules/module_seg_vit.py:338-341) over many rows: ONE output tile, i.e. one workgroup walking all M rows (1.6 ms at
+        # M = 12544) - instead M / 64 batched problems of 64 rows each and a column sum of their partial results
+        S = M // 64
+        part = _empty((S, N * K), torch.float32, dy)
+        p_gemm(dy, x, part, N, K, 64, (1, _ld(dy)), (1, _ld(x)), K, nb1=S, bsA=(64 * _ld(dy), 0), bsB=(64 * _ld(x), 0),
+               bsC=(N * K, 0))
+        p_colsum(part, out=dw.view(N * K))
+        return dw
     p_gemm(dy, x, dw, N, K, M, (1, _ld(dy)), (1, _ld(x)), K, defer=defer)
     return dw
 
@@ -1565,6 +1576,44 @@ class EmbedFn(Function):
             dpos = torch.zeros(pshape, dtype=torch.float32, device=dout.device)
             dpos[:Lq] = dpos_l
         return None, dtable, dpos
+
+
+class ReconMixFn(Function):
+    """out (B,M,D) = a (B,M,8) @ x (B,8,D) in fp32 (reference modules/module_seg_vit.py:342: the token rows of the MAE branch rebuilt
+    from the 8 centers) as one pass over the output; backward da = dout x^T, dx = a^T dout in one kernel."""
+
+    @staticmethod
+    def forward(ctx, a, x):
+        B, M, G = a.shape
+        D = x.shape[2]
+        a, x = a.contiguous(), x.contiguous()
+        out = _empty((B, M, D), torch.float32, a)
+        L.check(L.load().segclip_recon_mix_fwd(L.ptr(a), L.ptr(x), L.ptr(out), B, M, G, D, L.stream()), "recon_mix_fwd")
+        ctx.save_for_backward(a, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, x = ctx.saved_tensors
+        B, M, G = a.shape
+        D = x.shape[2]
+        dout = dout.contiguous()
+        da = _empty((B, M, G), torch.float32, a)
+        dx = _empty((B, G, D), torch.float32, a)
+        L.check(L.load().segclip_recon_mix_bwd(L.ptr(a), L.ptr(x), L.ptr(dout), L.ptr(da), L.ptr(dx), B, M, G, D, L.stream()),
+                "recon_mix_bwd")
+        return da, dx
+
+
+_RECON_MIX = os.environ.get("SEGCLIP_RECON_MIX", "1") != "0"      # A/B: 0 = the batched exact-fp32 GEMM
+
+
+def recon_mix(a, x):
+    """a (B,M,G) @ x (B,G,D) -> (B,M,D), fp32: the dedicated kernel for G = 8, the batched GEMM otherwise."""
+    if (_RECON_MIX and a.dtype == torch.float32 and x.dtype == torch.float32 and a.dim() == 3 and x.dim() == 3 and a.shape[2] == 8
+            and x.shape[1] == 8 and x.shape[2] % 4 == 0 and 4 <= x.shape[2] <= 4096):
+        return ReconMixFn.apply(a, x)
+    return bmm(a, x, transB=False, out_dtype=torch.float32)
 
 
 class MeanCatFn(Function):

@@ -676,6 +676,32 @@ def test_mae_unshuffle(B, K, L, D):
         assert float(mt.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,M,D", [(5, 49, 768), (3, 196, 768), (2, 7, 40), (2, 70, 1024)])
+def test_recon_mix(B, M, D):
+    """a (B,M,8) @ x (B,8,D) (reference modules/module_seg_vit.py:342) as a dedicated kernel pair against torch.bmm in fp32."""
+    a = rnd(B, M, 8, seed=221).requires_grad_()
+    x = rnd(B, 8, D, seed=222).requires_grad_()
+    g = rnd(B, M, D, seed=223)
+    y = ops.recon_mix(a, x)
+    y.backward(g)
+    ar, xr = a.detach().clone().requires_grad_(), x.detach().clone().requires_grad_()
+    yr = torch.bmm(ar, xr)
+    yr.backward(g)
+    close(y, yr, 1e-5, 1e-5, "recon_mix forward")
+    close(a.grad, ar.grad, 1e-4, 1e-4 * D ** 0.5, "recon_mix da")
+    close(x.grad, xr.grad, 1e-4, 1e-4 * M ** 0.5, "recon_mix dx")
+
+
+def test_tiny_weight_gradient_over_many_rows():
+    """p_wgrad with an 8 x 8 result over 12544 fp32 rows (the Linear over the center axis in the MAE branch, reference
+    modules/module_seg_vit.py:338-341): 196 batched 64-row problems + a column sum instead of one workgroup walking every row."""
+    dy, x = rnd(12544, 8, seed=231), rnd(12544, 8, seed=232)
+    dw = ops.p_wgrad(dy, x)
+    close(dw, dy.t() @ x, 1e-4, 1e-2, "tiny weight gradient")
+    dy2, x2 = rnd(4000, 8, seed=233), rnd(4000, 8, seed=234)      # below the threshold: the general path
+    close(ops.p_wgrad(dy2, x2), dy2.t() @ x2, 1e-4, 1e-2, "tiny weight gradient, general path")
+
+
 def test_gumbel_noise_transform():
     """config.gumbel: torch's uniform draw, then -log(-log(clamp(u))) as one kernel - the values of the op-by-op expression
     (same generator state -> same noise as before), including the clamped end points."""
