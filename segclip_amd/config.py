@@ -16,7 +16,9 @@ overlap_towers: enqueue the text tower on a second HIP stream (concurrent with t
 text_after_blocks : with overlap_towers: the text tower is enqueued after this many vision blocks (host launch order;
                 0 = before the vision tower).  The host needs ~3 ms to enqueue the text tower: queued first, the vision
                 stream idles that long at the start of every step, and - autograd replays the recording order backwards -
-                again ~6 ms at the end of the backward pass (tools/stream_gaps.py)
+                again ~6 ms at the end of the backward pass (tools/stream_gaps.py).  The hook also cuts the vision tower's first
+                stack into two autograd nodes, i.e. it decides the weight-gradient groups: 3 + 7 blocks (7 x 108 tiles = 2.95 rounds
+                of 256 CUs, no K split) measured 36.80 / 36.82 ms per step against 37.04 / 37.04 for 4 + 6 (round 5; 2: 36.97, 5: 37.12, 6: 36.98)
 wgrad_group_blocks : bf16 mode, inside ResStackFn: the weight gradients of up to this many consecutive blocks run as ONE grouped
                 launch (ops.WgradGroup / segclip_wgrad_group) with few K ranges instead of 4 launches per block with 7-28 K
                 ranges each (64 MB of fp32 partial tiles per gradient); the partition of a stack into groups minimises the
@@ -76,7 +78,7 @@ import torch
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
-                 text_after_blocks=4, text_trim=False, text_trim_hint=None, fold_param_grads=__import__("os").environ.get("SEGCLIP_FOLD_GRADS", "1") != "0",
+                 text_after_blocks=3, text_trim=False, text_trim_hint=None, fold_param_grads=__import__("os").environ.get("SEGCLIP_FOLD_GRADS", "1") != "0",
                  wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP_DIST", "12")))
 _tls = threading.local()
 
