@@ -915,6 +915,8 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
     wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (wqkv, wo, wfc, wpr))
     qkv, _ = p_linear(y1, wqkv_c, bqkv)
     o = _empty((M, D), act_dtype, x2)
+    if M > B * T:                 # row-padded stack (ResStackFn): the attention kernel writes the B * T token rows only
+        o[B * T:].zero_()
     from . import config as _cfg
     ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, (T * 3 * D, 3 * D), (T * 3 * D, 3 * D),
                     (T * 3 * D, 3 * D), (T * D, D), 1.0 / math.sqrt(hd), causal, 0, D, 2 * D,
@@ -954,7 +956,7 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     -> (dx fp32 or None, dx bf16 or None, the 12 parameter gradients)"""
     (x2, ln1w, mean1, rstd1, y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, mean2, rstd2, y2, wfc_c, u, h, wpr_c) = saved
     B, T, D, n_head, causal, act, act_dtype = cfg
-    M = B * T
+    M = x2.shape[0]               # B * T, or that rounded up to 128 rows in a row-padded stack (pad rows: zero gradients)
     hd = D // n_head
     bf = act_dtype == torch.bfloat16
     # bf16 mode: the residual-stream gradients feed the GEMMs as bf16 copies (all GEMMs then run on the LDS-DMA
@@ -1017,6 +1019,8 @@ def _resblock_bwd(saved, cfg, klen, gslots, vslots, need, g, g16, chain, overlap
     do = p_dgrad(dx1_16, wo_c, act_dtype)
     dwo = wgrad(dx1_16, o, _slot_out(so, (D, D))) if need[5] else None
     dqkv = _empty((M, 3 * D), act_dtype, x2)
+    if M > B * T:
+        dqkv[B * T:].zero_()      # the attention backward writes the token rows; a pad row must contribute exact zeros downstream
     s3 = (T * 3 * D, 3 * D)
     ad = _attn_desc(qkv, qkv, qkv, o, B, n_head, T, T, hd, s3, s3, s3, (T * D, D), 1.0 / math.sqrt(hd), causal,
                     0, D, 2 * D, klen=klen)
@@ -1155,6 +1159,15 @@ class ResStackFn(Function):
         nblk = len(params) // ResStackFn.NP
         cur = x.contiguous().view(B * T, D)
         from . import config as _cfg
+        # config.pad_rows (bf16 mode): a token-row count that is not a multiple of 128 (the text tower's B x 77 at any batch
+        # that is not a multiple of 128 samples) keeps every GEMM of the stack off the 256 x 256-tile kernel, off the one-byte
+        # derivative and - when it is not a multiple of 64 either - off the grouped weight gradients.  The stack then runs on
+        # M rounded up to 128 rows: pad rows start as zeros, every operator of a block is row-wise except attention (which
+        # only touches the B * T token rows; its outputs' pad rows are zeroed), so pad rows stay finite, carry exactly zero
+        # gradients and contribute exact zeros to every weight / bias gradient.
+        M = B * T
+        Mp = -(-M // 128) * 128 if (act_dtype == torch.bfloat16 and bool(_cfg.pad_rows) and M % 128 != 0 and M >= _PAD_ROWS_MIN) else M
+        ctx.Mp = Mp
         # config.bf16_resid (bf16 mode): the residual stream is bf16 between the blocks of the stack (the out_proj / c_proj
         # epilogues read and write 2 instead of 4 bytes per element and run on gemm_bf16_pq.hip; every LayerNorm pass reads
         # 2 bytes less).  Input / output of the node: fp32, or bf16 when the neighbouring node is a stack too (keep16).
@@ -1164,10 +1177,17 @@ class ResStackFn(Function):
             cur = p_cast(cur, torch.bfloat16)
         elif not resid16 and cur.dtype != torch.float32:
             cur = p_cast(cur, torch.float32)
+        if Mp != M:
+            padded = _empty((Mp, D), cur.dtype, cur)
+            padded[:M].copy_(cur)
+            padded[M:].zero_()
+            cur = padded
         saved = []
         for b in range(nblk):
             cur, sv = _resblock_fwd(cur, params[b * 12:(b + 1) * 12], B, T, n_head, causal, act, eps, act_dtype, klen)
             saved.extend(sv)
+        if Mp != M:
+            cur = cur[:M]
         ctx.save_for_backward(*saved)
         ctx.cfg = (B, T, D, n_head, causal, act, act_dtype)
         ctx.klen, ctx.nblk = klen, nblk
@@ -1189,11 +1209,18 @@ class ResStackFn(Function):
     def backward(ctx, g):
         B, T, D, n_head, causal, act, act_dtype = ctx.cfg
         M, nblk = B * T, ctx.nblk
+        Mp = ctx.Mp
         bf = act_dtype == torch.bfloat16
         st = getattr(g, "_segclip_bf16", None)
         if st is not None and (st.numel() != g.numel() or st.device != g.device or not g.is_contiguous()):
             st = None
         g = g.contiguous().view(M, D)
+        if Mp != M:               # row-padded stack: the gradient of a pad row is zero
+            st = None
+            padded = _empty((Mp, D), g.dtype, g)
+            padded[:M].copy_(g)
+            padded[M:].zero_()
+            g, M = padded, Mp
         cur16 = st.view(M, D) if (st is not None and bf) else None
         if bf and cur16 is None and g.dtype == torch.bfloat16:   # bf16 output of the node (keep16)
             cur16 = g
@@ -1215,10 +1242,10 @@ class ResStackFn(Function):
         wg, sizes = None, []
         if ctx.wgrad_group > 1 and ctx.cfg[-1] == torch.bfloat16 and not ctx.overlap_wgrad and nblk > 1:
             Dm, F4 = ctx.params[2].shape[1], ctx.params[8].shape[0]
-            if Dm % 256 == 0 and F4 % 256 == 0 and (B * T) % 64 == 0:
+            if Dm % 256 == 0 and F4 % 256 == 0 and Mp % 64 == 0:
                 gmax = ctx.wgrad_group if all(s is None for s in ctx.slots) else min(ctx.wgrad_group, ctx.wgrad_group_dist)
                 tiles_blk = (4 * Dm * Dm + 2 * F4 * Dm) // 65536
-                sizes = wgrad_group_plan(nblk, tiles_blk, (B * T) // 64, gmax)
+                sizes = wgrad_group_plan(nblk, tiles_blk, Mp // 64, gmax)
                 wg = WgradGroup() if max(sizes) > 1 else None
         left = sizes.pop(0) if wg is not None else 0
         grq = ReduceQueue() if (wg is not None and rside is None and _SHARED_RQ) else None
@@ -1262,6 +1289,9 @@ class ResStackFn(Function):
             keep.clear()
         if rside is not None:
             torch.cuda.current_stream().wait_stream(rside)     # the parameter gradients are complete when the node returns
+        if Mp != B * T:                      # row-padded stack: back to the token rows
+            cur16 = cur16[:B * T] if cur16 is not None else None
+            cur32 = cur32[:B * T] if cur32 is not None else None
         if ctx.chain and ctx.in_dtype == torch.bfloat16:
             dx = cur16                       # the producer is a stack with a bf16 output: no cast, no side copy
         elif ctx.chain:
@@ -1605,6 +1635,9 @@ class ReconMixFn(Function):
         return da, dx
 
 
+# config.pad_rows applies from this many token rows on: below it a step is bound by the host's launch rate (per-GPU batch 64:
+# 13.5 ms of enqueue per step), where the ~50 extra small launches of a padded tower cost more than the faster kernels return
+_PAD_ROWS_MIN = int(os.environ.get("SEGCLIP_PAD_ROWS_MIN", "6144"))
 _RECON_MIX = os.environ.get("SEGCLIP_RECON_MIX", "1") != "0"      # A/B: 0 = the batched exact-fp32 GEMM
 
 

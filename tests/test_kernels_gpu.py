@@ -857,6 +857,48 @@ def test_res_stack_folds_gradients_of_shared_parameters(dtype):
             assert torch.allclose(z, 2 * u, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_res_stack_row_padding(causal, monkeypatch):
+    """config.pad_rows: a stack whose B x T is not a multiple of 128 (the text tower at 96 samples: 96 x 77 = 7392) runs on the
+    row count rounded up to 128 - the 256 x 256-tile GEMM kernel, the one-byte derivative, the grouped weight gradients.  Pad rows
+    are zeros going in and carry zero gradients: outputs and every gradient must agree with the unpadded stack to bf16 rounding
+    (the two runs use different GEMM kernels), and nothing of a pad row may leak (an uninitialised pad row would show up as
+    NaN / Inf or as a large error in a weight gradient)."""
+    import segclip_amd
+    B, T, D, H, nblk = 16, 77, 512, 8, 2
+    assert (B * T) % 128 != 0
+    monkeypatch.setattr(ops, "_PAD_ROWS_MIN", 1024)      # (the default threshold is a per-GPU batch of 80 text samples)
+    torch.manual_seed(13)
+    blocks = []
+    for _ in range(nblk):
+        P = [torch.ones(D) + 0.1 * torch.randn(D), 0.1 * torch.randn(D), torch.randn(3 * D, D) * D ** -0.5,
+             0.1 * torch.randn(3 * D), torch.randn(D, D) * D ** -0.5, 0.1 * torch.randn(D),
+             torch.ones(D) + 0.1 * torch.randn(D), 0.1 * torch.randn(D), torch.randn(4 * D, D) * D ** -0.5,
+             0.1 * torch.randn(4 * D), torch.randn(D, 4 * D) * (4 * D) ** -0.5, 0.1 * torch.randn(D)]
+        blocks.append([p.to(DEV).requires_grad_() for p in P])
+    x0 = torch.randn(B, T, D, device=DEV)
+    gout = torch.randn(B, T, D, device=DEV)
+
+    def run(pad):
+        for P in blocks:
+            for p in P:
+                p.grad = None
+        x = x0.clone().requires_grad_()
+        with segclip_amd.config.scope(pad_rows=pad):
+            y = ops.res_stack(x, blocks, H, causal, ops.ACT_QUICK_GELU, 1e-5, BF)
+        assert y.shape == (B, T, D)
+        y.backward(gout)
+        return y.detach(), x.grad.clone(), [[p.grad.clone() for p in P] for P in blocks]
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    pairs = [(y0, y1), (dx0, dx1)] + [(u, v) for a, b in zip(g0, g1) for u, v in zip(a, b)]
+    for u, v in pairs:
+        assert bool(torch.isfinite(v).all())
+        rel = float((u - v).norm() / u.norm().clamp_min(1e-12))
+        assert rel <= 2e-2, rel
+
+
 def test_res_stack_bf16_chain_depth12_width768():
     """The bf16 residual-gradient chain (config.bf16_resgrad, the mode the bench runs) at the DEPTH and WIDTH of the
     vision tower: 12 blocks, D = 768, against the same stack with the fp32 residual gradient and against the exact-f32
