@@ -24,7 +24,8 @@ b dist_bf16wire --no-cpu-baseline --no-roofline --no-parity-leg --force-dist --w
 b plain_ref2 --no-cpu-baseline --no-roofline --no-parity-leg
 b vitl14 --no-cpu-baseline --no-traffic --no-parity-leg --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
 b text_trim --no-cpu-baseline --no-roofline --no-parity-leg --text-trim
-for bsz in 64 128 512; do b b$bsz --no-cpu-baseline --no-roofline --no-parity-leg --batch $bsz; done
+for bsz in 64 96 128 192 512; do b b$bsz --no-cpu-baseline --no-roofline --no-parity-leg --batch $bsz; done
+SEGCLIP_PAD_ROWS=0 b b96_pad_off --no-cpu-baseline --no-roofline --no-parity-leg --batch 96
 # same-box A/B of the grouped weight gradients (config.wgrad_group_blocks): one launch per gradient vs the default, twice
 # (library kernel-selection switches need SEGCLIP_TUNING=1)
 # same-box A/Bs, twice each: the half-tile tail of gemm_bf16_pq.hip (SEGCLIP_PQ_HALF=0 = full tiles only), B = 256 and B = 128

@@ -34,7 +34,9 @@ for n, desc in (("gb2048", "--global-batch 2048 (SURVEY 8d strong-scaling base o
                 ("vitl14", "--spec vitl14_336 --batch 128 --attn-fp8 off (BASELINE configs[4], bf16 attention)"),
                 ("vitl14_fp8", "--spec vitl14_336 --batch 128 --attn-fp8 on"), ("plain_ref", "default configuration right before the `dist` / `dist_bf16wire` lines (same box)"),
                 ("plain_ref2", "the same, after the dist lines"),
-                ("b64", "--batch 64"), ("b128", "--batch 128"), ("b512", "--batch 512"),
+                ("b64", "--batch 64"), ("b96", "--batch 96 (the reference recipe's per-GPU batch; config.pad_rows pads the text tower's 7392 rows to 7424; r05: b96 / b96_pad_off / b192 were added after the round's pass, on another box)"),
+                ("b96_pad_off", "--batch 96 SEGCLIP_PAD_ROWS=0 (the text tower on the ragged-edge kernels), same box"),
+                ("b128", "--batch 128"), ("b192", "--batch 192"), ("b512", "--batch 512"),
                 ("text_trim", "--text-trim: config.text_trim in the timed region (opt-in; causal text tower up to the batch's last EOT)"),
                 ("attn_fwd_old_a", "SEGCLIP_ATTN_FWD_PF=0 (one workgroup per item attention forward), same box, --steps 30"),
                 ("attn_fwd_pf_a", "default (persistent attention forward), same box, --steps 30"),
