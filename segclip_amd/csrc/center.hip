@@ -230,10 +230,13 @@ __global__ __launch_bounds__(1024) void recon_mix_bwd_kernel(const float* __rest
 // assignment logits attn[b][g][t] = q[b][g][:] . k[b][t][:]  (reference modules/module_seg_vit.py:304, un-scaled), fp32
 template <int NCG>
 __global__ __launch_bounds__(256) void center_logits_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                float* __restrict__ attn, int T) {
-  extern __shared__ float sm[];                 // [T][CG]
+                                                                float* __restrict__ attn, int T, int tchunk) {
+  extern __shared__ float sm[];                 // [tchunk][CG]
   constexpr int D = NCG * 256;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // blockIdx.y: a token range of the sample (small inference batches: one workgroup per sample leaves most CUs idle; every
+  // logit is its own dot product, so the split does not change a bit)
+  const int tb = blockIdx.y * tchunk, te = tb + tchunk < T ? tb + tchunk : T;
   f32x4 qr[NCG][CG];
 #pragma unroll
   for (int kk = 0; kk < NCG; ++kk)
@@ -241,15 +244,15 @@ __global__ __launch_bounds__(256) void center_logits_fwd_kernel(const float* __r
     for (int g = 0; g < CG; ++g) qr[kk][g] = *reinterpret_cast<const f32x4*>(q + ((int64_t)b * CG + g) * D + kk * 256 + lane * 4);
   const float* kb = k + (int64_t)b * T * D + lane * 4;
   f32x4 xn[NCG];
-  if (wave < T) {
+  if (tb + wave < te) {
 #pragma unroll
-    for (int kk = 0; kk < NCG; ++kk) xn[kk] = *reinterpret_cast<const f32x4*>(kb + (int64_t)wave * D + kk * 256);
+    for (int kk = 0; kk < NCG; ++kk) xn[kk] = *reinterpret_cast<const f32x4*>(kb + (int64_t)(tb + wave) * D + kk * 256);
   }
-  for (int t = wave; t < T; t += 4) {
+  for (int t = tb + wave; t < te; t += 4) {
     f32x4 x[NCG];
 #pragma unroll
     for (int kk = 0; kk < NCG; ++kk) x[kk] = xn[kk];
-    if (t + 4 < T) {
+    if (t + 4 < te) {
 #pragma unroll
       for (int kk = 0; kk < NCG; ++kk) xn[kk] = *reinterpret_cast<const f32x4*>(kb + (int64_t)(t + 4) * D + kk * 256);
     }
@@ -261,12 +264,13 @@ __global__ __launch_bounds__(256) void center_logits_fwd_kernel(const float* __r
       for (int kk = 0; kk < NCG; ++kk) p[g] += dot4(qr[kk][g], x[kk]);
     }
     const float s = wave_sum8(p, lane);
-    if ((lane & 7) == 0) sm[(int64_t)t * CG + (lane >> 3)] = s;
+    if ((lane & 7) == 0) sm[(int64_t)(t - tb) * CG + (lane >> 3)] = s;
   }
   __syncthreads();
-  for (int i = tid; i < CG * T; i += blockDim.x) {
-    const int g = i / T, t = i - g * T;
-    attn[((int64_t)b * CG + g) * T + t] = sm[(int64_t)t * CG + g];
+  const int n = te - tb;
+  for (int i = tid; i < CG * n; i += blockDim.x) {
+    const int g = i / n, t = i - g * n;
+    attn[((int64_t)b * CG + g) * T + tb + t] = sm[(int64_t)t * CG + g];
   }
 }
 // dq[b][g][:] = sum_t dl[b][g][t] k[b][t][:] ; dk[b][t][:] = sum_g dl[b][g][t] q[b][g][:]   (fp32)
@@ -543,9 +547,15 @@ extern "C" int segclip_center_logits_fwd(const float* q, const float* k, float* 
     return SEGCLIP_ERR_UNSUPPORTED;
   }
   if (B == 0) return 0;
-  const size_t lds = (size_t)T * CG * sizeof(float);
-  if (D == 768) hipLaunchKernelGGL(center_logits_fwd_kernel<3>, dim3((unsigned)B), dim3(256), lds, ST, q, k, attn, (int)T);
-  else hipLaunchKernelGGL(center_logits_fwd_kernel<4>, dim3((unsigned)B), dim3(256), lds, ST, q, k, attn, (int)T);
+  // fewer samples than CUs (inference batches): token ranges of at least 64 tokens over blockIdx.y
+  int nchunk = B >= 128 ? 1 : (int)((255 + B) / B);
+  if (nchunk > (int)((T + 63) / 64)) nchunk = (int)((T + 63) / 64);
+  if (nchunk < 1) nchunk = 1;
+  const int tchunk = (int)((T + nchunk - 1) / nchunk);
+  nchunk = (int)((T + tchunk - 1) / tchunk);
+  const size_t lds = (size_t)tchunk * CG * sizeof(float);
+  if (D == 768) hipLaunchKernelGGL(center_logits_fwd_kernel<3>, dim3((unsigned)B, (unsigned)nchunk), dim3(256), lds, ST, q, k, attn, (int)T, tchunk);
+  else hipLaunchKernelGGL(center_logits_fwd_kernel<4>, dim3((unsigned)B, (unsigned)nchunk), dim3(256), lds, ST, q, k, attn, (int)T, tchunk);
   SEGCLIP_CHECK_LAUNCH("center_logits_fwd");
   return 0;
 }

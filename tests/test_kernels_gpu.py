@@ -1115,7 +1115,7 @@ def test_segment_mean_of_center_stage(dtype, B, T, D):
     close(h1.grad, h2.grad, 1e-4, 1e-4 * D ** 0.5, "dhard")
 
 
-@pytest.mark.parametrize("B,T,D", [(4, 196, 768), (2, 576, 1024), (3, 48, 768)])
+@pytest.mark.parametrize("B,T,D", [(4, 196, 768), (2, 576, 1024), (3, 48, 768), (16, 784, 768), (130, 196, 768)])
 def test_center_assignment_logits_token_loop(B, T, D):
     """attn = q k^T (un-scaled, fp32; modules/module_seg_vit.py:304) and its backward as per-sample token loops
     (ops.CenterLogitsFn, the bf16 mode's path) against torch in fp64."""
