@@ -616,6 +616,7 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 #include "attention_sp.inc"
 #include "attention_pf.inc"
 #include "attention_spl.inc"
+#include "attention_dqw.inc"
 #include "attention_sq.inc"
 #include "attention_stream.inc"
 // e4m3 forward (BASELINE configs[4] as first read): forward-only, non-scaled e4m3 MFMA = the bf16 rate, measured SLOWER than the
@@ -702,6 +703,22 @@ int launch_fwd_pf(const FwdArgs& a, int nitems, hipStream_t stream) {
   const int grid = nitems < cap ? nitems : cap;
   hipLaunchKernelGGL((attn_fwd_pf_kernel<NT, CAUSAL, ABL>), dim3((unsigned)grid), dim3((NT + 1) * 64), lds, stream, a, nitems);
   SEGCLIP_CHECK_LAUNCH("attn_fwd_pf");
+  return 0;
+}
+
+// streaming backward with a dQ wave (attention_dqw.inc): one workgroup of NT + 1 waves per CU walks its share of the items
+template <int NT>
+int launch_bwd_dqw(const BwdArgs& a, int ncu, int dev, hipStream_t stream) {
+  static bool attr_set[64] = {};
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dqw_bf16_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SEGCLIP_REQUIRE(e == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    attr_set[dev] = true;
+  }
+  const int grid = a.nitems < ncu ? a.nitems : ncu;
+  hipLaunchKernelGGL((attn_bwd_dqw_bf16_kernel<NT>), dim3((unsigned)grid), dim3((NT + 1) * 64), bwd_dqw_lds_bytes<NT>(), stream, a);
+  SEGCLIP_CHECK_LAUNCH("attn_bwd_dqw_bf16");
   return 0;
 }
 
@@ -898,6 +915,11 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
       if (grid_env > 0) per_cu = grid_env;
       int64_t grid = grid_env == 0 ? a.nitems : (int64_t)ncu * per_cu;
       if (grid > a.nitems) grid = a.nitems;
+      // vision tower (no mask, head_dim 64, 7 tiles, padded rows in the last tile): the query tiles as a stream with a dQ wave
+      // (attention_dqw.inc, round 6); SEGCLIP_ATTN_BWD_DQW=0 keeps the kernels below
+      static const int use_dqw = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_DQW"); return e ? atoi(e) : 1; }();
+      if (use_dqw && !masked && d->hd == 64 && tiles == 7 && d->Tq % 32 >= 1 && d->Tq % 32 <= 30)
+        return launch_bwd_dqw<7>(a, ncu, dev, stream);
       // vision tower (no mask, 5-7 tiles): the variant whose memory traffic is issued by a loader wave (attention_spl.inc);
       // SEGCLIP_ATTN_BWD_SPL=0 keeps attention_sp.inc
       // attention_sq.inc: the query tiles as a stream (round 5; SEGCLIP_ATTN_BWD_SQ=1)
