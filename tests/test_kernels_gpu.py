@@ -329,6 +329,11 @@ def _attn_ref(q, k, v, H, causal):
                                              # more (batch, head) items than the persistent backward grid has workgroups:
                                              # every workgroup walks 2-3 items with the next item's loads prefetched
                                              (48, 196, 12, 64, False), (160, 77, 8, 64, True),
+                                             # the streaming backward with a dQ wave (attention_dqw.inc: 7 tiles, padded rows in the last
+                                             # one): first / last admissible lengths, one item, items not a multiple of the grid; 223 and 224
+                                             # tokens have no two padded rows for the token sums and stay on the loader-wave kernel
+                                             (3, 193, 2, 64, False), (2, 222, 3, 64, False), (1, 197, 1, 64, False), (30, 200, 12, 64, False),
+                                             (3, 223, 2, 64, False), (2, 224, 2, 64, False),
                                              # > 256 tokens: the streaming backward (ViT-L/14 at 336^2: 576 patches)
                                              (2, 576, 16, 64, False), (1, 300, 2, 64, True), (1, 784, 3, 64, False)])
 def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
