@@ -81,11 +81,30 @@ import types
 
 import torch
 
+_warned_env = set()
+
+
+def tuning_env(name, default):
+    """A/B switch read from the environment.  Honoured only with SEGCLIP_TUNING=1 (the same gate as the native library's
+    kernel-selection variables, csrc/common.h): a production process cannot have its kernels re-routed by a stray variable,
+    and one that tries is told so once per variable."""
+    import os
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    if os.environ.get("SEGCLIP_TUNING", "0") in ("", "0"):
+        if name not in _warned_env:
+            _warned_env.add(name)
+            print(f"segclip_amd: {name}={v} ignored (tuning switches need SEGCLIP_TUNING=1)", file=sys.stderr)
+        return default
+    return v
+
+
 _DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
-                 aux_u8=__import__("os").environ.get("SEGCLIP_AUX_U8", "1") != "0",
-                 text_after_blocks=3, text_trim=False, text_trim_hint=None, pad_rows=__import__("os").environ.get("SEGCLIP_PAD_ROWS", "1") != "0", fold_param_grads=__import__("os").environ.get("SEGCLIP_FOLD_GRADS", "1") != "0",
-                 wgrad_group_blocks=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=int(__import__("os").environ.get("SEGCLIP_WGRAD_GROUP_DIST", "12")))
+                 aux_u8=tuning_env("SEGCLIP_AUX_U8", "1") != "0",
+                 text_after_blocks=3, text_trim=False, text_trim_hint=None, pad_rows=tuning_env("SEGCLIP_PAD_ROWS", "1") != "0", fold_param_grads=tuning_env("SEGCLIP_FOLD_GRADS", "1") != "0",
+                 wgrad_group_blocks=int(tuning_env("SEGCLIP_WGRAD_GROUP", "12")), wgrad_group_blocks_dist=int(tuning_env("SEGCLIP_WGRAD_GROUP_DIST", "12")))
 _tls = threading.local()
 
 

@@ -302,6 +302,11 @@ class GradSync(nn.Module):
                 keep.append((ev, host, n))
         self._verdicts = keep
 
+    def drain(self):
+        """Read every posted cross-rank agreement (blocking).  Call before a host decision that depends on the pass having been
+        exchanged consistently - a checkpoint, the end of training -: verdicts posted in the last pass are otherwise never read."""
+        self.check_collectives(block=True)
+
     def _finalize(self):
         self._callback_queued = False
         if self._verdicts:
@@ -328,6 +333,12 @@ class GradSync(nn.Module):
                     # POSTED here and read when it has arrived (round 5; it was a blocking host read in the first passes:
                     # the device idled at the start of the next step while the host waited for the end of this one)
                     self._post_verdict()
+                    if self._late:
+                        # ... except on a rank that is about to enqueue late exchanges: it reads the verdict FIRST (blocking).
+                        # A rank with no late gradient enqueues nothing extra and may read lazily; on a disagreement the rank
+                        # that would have queued extra all-reduces (which pair with the other ranks' NEXT bucket exchange:
+                        # a hang or silent corruption) raises here instead, the others at their next read.
+                        self.check_collectives(block=True)
                 elif self._late:
                     raise RuntimeError(
                         f"GradSync: {len(self._late)} parameter(s) received a gradient for the first time after the bucket "

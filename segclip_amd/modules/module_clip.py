@@ -3,6 +3,8 @@ ln_final, text_projection, logit_scale)."""
 from typing import Tuple, Union
 
 import numpy as np
+import weakref
+
 import torch
 from torch import nn
 
@@ -111,12 +113,15 @@ class CLIP(CLIP_Module):
         hint = config.text_trim_hint
         if hint is not None:
             return max(1, min(int(hint), text.shape[1]))
-        key = (text.data_ptr(), text._version, tuple(text.shape))
+        # cached per id TENSOR OBJECT (weak reference + version counter), never per address: a data loader hands over a fresh
+        # tensor every step, and the caching allocator very often gives it the address the previous batch just freed - an
+        # (address, version, shape) key then returned the OLD batch's length, cut the ids in front of a later EOT and argmax
+        # picked a wrong position, silently.  One host synchronisation per new id tensor.
         c = getattr(self, "_trim_cache", None)
-        if c is None or c[0] != key:
-            c = (key, int(text.argmax(dim=-1).max()) + 1)      # one host synchronisation per new id tensor
+        if c is None or c[0]() is not text or c[1] != text._version:
+            c = (weakref.ref(text), text._version, int(text.argmax(dim=-1).max()) + 1)
             self._trim_cache = c
-        return max(1, min(c[1], text.shape[1]))
+        return max(1, min(c[2], text.shape[1]))
 
     def encode_text_eot(self, text):
         """Training fast path: only the pooled (EOT) feature.  config.text_trim: the causal tower runs on the positions up to

@@ -18,6 +18,7 @@ import torch.distributed as dist
 from torch.autograd import Function
 
 from . import _lib as L
+from .config import tuning_env as _tenv
 
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = L.ACT_NONE, L.ACT_QUICK_GELU, L.ACT_GELU_ERF
 
@@ -195,8 +196,8 @@ def _wgrad_group_plan(nblk, tiles_blk, ksteps, gmax):
     return best[nblk][1]
 
 
-_PQ_TAIL_ENV = os.environ.get("SEGCLIP_PQ_TAIL", "0") not in ("", "0")
-_SHARED_RQ = os.environ.get("SEGCLIP_SHARED_RQ", "1") != "0"   # A/B: one reduce queue per weight-gradient group (1) or per block (0)
+_PQ_TAIL_ENV = _tenv("SEGCLIP_PQ_TAIL", "0") not in ("", "0")
+_SHARED_RQ = _tenv("SEGCLIP_SHARED_RQ", "1") != "0"   # A/B: one reduce queue per weight-gradient group (1) or per block (0)
 
 
 def _empty(shape, dtype, like):
@@ -208,7 +209,7 @@ def _empty(shape, dtype, like):
 # forward with its two outputs runs 385 -> 312 us, the c_proj data gradient 324 -> 290 us, and the GEMMs that read these
 # tensors as their A operand 2-5 % faster (M = 50176; tools/debug/gemm_ldc_probe2.py).  SEGCLIP_HIDDEN_PAD = extra
 # elements per row (0 = dense).
-_HIDDEN_PAD = int(os.environ.get("SEGCLIP_HIDDEN_PAD", "512"))
+_HIDDEN_PAD = int(_tenv("SEGCLIP_HIDDEN_PAD", "512"))
 
 
 def _empty_pitched(shape, dtype, like):
@@ -399,7 +400,7 @@ def p_wgrad(dy, x, w_kn=False, out=None, defer=None):
         x = p_cast(x, dy.dtype)  # only the A operand may be fp32 on the bf16 path
     dw = out if out is not None else _empty((N, K), torch.float32, dy)
     if (dy.dtype == torch.float32 and x.dtype == torch.float32 and N * K <= 1024 and M >= 4096 and M % 64 == 0
-            and dw.is_contiguous()):
+            and dw.is_contiguous() and defer is None):   # (the batched form has nothing to defer: a caller that wants to takes the plain path)
         # a tiny weight (the 8 x 8 Linear over the center axis of the MAE branch's ReconstructLayer, reference
         # modules/module_seg_vit.py:338-341) over many rows: ONE output tile, i.e. one workgroup walking all M rows (1.6 ms at
         # M = 12544) - instead M / 64 batched problems of 64 rows each and a column sum of their partial results
@@ -554,7 +555,7 @@ def _reduce_stream():
 # config.overlap_wgrad experiments (read once): SEGCLIP_WGRAD_JOIN=stack joins the weight-gradient stream once per
 # ResStackFn backward instead of once per block (the tensors it reads are kept alive until then); the stream's priority
 # comes from SEGCLIP_WGRAD_PRIO (segclip_amd/streams.py)
-_WGRAD_JOIN_STACK = os.environ.get("SEGCLIP_WGRAD_JOIN", "block") == "stack"
+_WGRAD_JOIN_STACK = _tenv("SEGCLIP_WGRAD_JOIN", "block") == "stack"
 
 
 def interp_pos_table(table, h, w):
@@ -1076,6 +1077,7 @@ class ResBlockFn(Function):
         ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
         ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
         ctx.vslots = tuple(_slot_of(w) for w in (ln1w, ln1b, bqkv, bo, ln2w, ln2b, bfc, bpr))
+        _GradFold.other.add(id(ln1w))                        # a producer that does not fold: its block's gradients go the engine's way
         return xo.view(B, T, D)
 
     @staticmethod
@@ -1105,12 +1107,17 @@ class _GradFold:
     armed = -1
     first = {}
     uses = {}      # id(first parameter of a block) -> ResStackFn forwards over that block since the last advance(): armed from 2
+    other = set()  # id(first parameter of a block) that a NON-stack node (ResBlockFn) used since the last advance(): never folded.
+    #                Folding is only sound while every producer of a parameter's gradient in the pass is a folding ResStackFn node: a
+    #                gradient delivered by another producer in between makes the engine build a NEW sum tensor (the alias below raises
+    #                the storage's use count), and a later in-place add would land in the stale one
 
     @classmethod
     def advance(cls):
         cls.epoch += 1
         cls.first.clear()
         cls.uses.clear()
+        cls.other.clear()
 
     @classmethod
     def take(cls, p, gr, adds):
@@ -1269,7 +1276,7 @@ class ResStackFn(Function):
                     grq.flush()
                 left = sizes.pop(0) if sizes else nblk
             for b_, P_, sl_, grads_ in pending:
-                fold = ctx.fold and _GradFold.uses.get(id(P_[0]), 0) > 1      # only blocks a second node of this pass shares
+                fold = ctx.fold and _GradFold.uses.get(id(P_[0]), 0) > 1 and id(P_[0]) not in _GradFold.other   # only blocks a second STACK node of this pass shares
                 for i, (p, gr, slot) in enumerate(zip(P_, grads_, sl_)):
                     if gr is None:
                         continue
@@ -1637,8 +1644,8 @@ class ReconMixFn(Function):
 
 # config.pad_rows applies from this many token rows on: below it a step is bound by the host's launch rate (per-GPU batch 64:
 # 13.5 ms of enqueue per step), where the ~50 extra small launches of a padded tower cost more than the faster kernels return
-_PAD_ROWS_MIN = int(os.environ.get("SEGCLIP_PAD_ROWS_MIN", "6144"))
-_RECON_MIX = os.environ.get("SEGCLIP_RECON_MIX", "1") != "0"      # A/B: 0 = the batched exact-fp32 GEMM
+_PAD_ROWS_MIN = int(_tenv("SEGCLIP_PAD_ROWS_MIN", "6144"))
+_RECON_MIX = _tenv("SEGCLIP_RECON_MIX", "1") != "0"      # A/B: 0 = the batched exact-fp32 GEMM
 
 
 def recon_mix(a, x):

@@ -137,6 +137,8 @@ def save_model(epoch, args, model, optimizer, tr_loss, scaler=None, type_name=""
     """main_task_align.py:258-273: bare model state_dict -> pytorch_model.bin.<epoch>, optimizer/epoch/loss ->
     pytorch_opt.bin.<epoch> (same file names and dictionary keys, so either implementation can resume the other)."""
     import os
+    if hasattr(model, "drain"):
+        model.drain()   # a checkpoint is a host decision: no unread GradSync verdict behind it
     tag = "{}{}".format("" if type_name == "" else type_name + ".", epoch)
     model_file = os.path.join(args.output_dir, "pytorch_model.bin." + tag)
     opt_file = os.path.join(args.output_dir, "pytorch_opt.bin." + tag)
@@ -258,5 +260,7 @@ def train_epoch(epoch, args, model, train_dataloader, device, n_gpu, optimizer, 
                         getattr(args, "epochs", "?"), step + 1, len(train_dataloader), lrs, st["last_loss"],
                         st["grad_norm"], (time.time() - start_time) / (log_step * acc))
             start_time = time.time()
+    if hasattr(model, "drain"):
+        model.drain()   # GradSync: read the cross-rank agreements posted in the last passes (tail.read() below waits for the device anyway)
     total = tail.read()["loss_sum"] - start_sum + (float(partial) if partial is not None else 0.0)
     return total / max(n_batches, 1), global_step

@@ -25,7 +25,7 @@ b plain_ref2 --no-cpu-baseline --no-roofline --no-parity-leg
 b vitl14 --no-cpu-baseline --no-traffic --no-parity-leg --spec vitl14_336 --batch 128 --steps 5 --warmup 2 --attn-fp8 off
 b text_trim --no-cpu-baseline --no-roofline --no-parity-leg --text-trim
 for bsz in 64 96 128 192 512; do b b$bsz --no-cpu-baseline --no-roofline --no-parity-leg --batch $bsz; done
-SEGCLIP_PAD_ROWS=0 b b96_pad_off --no-cpu-baseline --no-roofline --no-parity-leg --batch 96
+SEGCLIP_TUNING=1 SEGCLIP_PAD_ROWS=0 b b96_pad_off --no-cpu-baseline --no-roofline --no-parity-leg --batch 96
 # same-box A/B of the grouped weight gradients (config.wgrad_group_blocks): one launch per gradient vs the default, twice
 # (library kernel-selection switches need SEGCLIP_TUNING=1)
 # same-box A/Bs, twice each: the half-tile tail of gemm_bf16_pq.hip (SEGCLIP_PQ_HALF=0 = full tiles only), B = 256 and B = 128
@@ -35,7 +35,7 @@ for rep in a b; do
   b half_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --steps 30 --warmup 8
   SEGCLIP_TUNING=1 SEGCLIP_PQ_HALF=0 b b128_half_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
   b b128_half_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --batch 128 --steps 30 --warmup 8
-  SEGCLIP_FOLD_GRADS=0 b full_fold_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
+  SEGCLIP_TUNING=1 SEGCLIP_FOLD_GRADS=0 b full_fold_off_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
   b full_fold_on_$rep --no-cpu-baseline --no-roofline --no-parity-leg --full-loss
 done
 timeout 400 python tools/bench_pq_half.py 2>&1 | grep -v "$F" | grep -v "^check\|relerr" > $OUT/gemm_half_tile.txt
