@@ -462,12 +462,27 @@ def main():
             with segclip_amd.noise_injection(items):
                 l_ = step()
             torch.cuda.synchronize()
-            return float(l_.detach()), model.last_logits[0].float().clone(), model.last_mid_states["hard_idx"].clone()
+            soft = model.last_mid_states["attns"][0]["soft_attn"] if model.last_mid_states.get("attns") else None
+            return (float(l_.detach()), model.last_logits[0].float().clone(), model.last_mid_states["hard_idx"].clone(),
+                    soft.float().clone() if soft is not None else None)
 
-        lb, tb, hb = probe()
+        lb, tb, hb, _ = probe()
         segclip_amd.set_compute_dtype(torch.float32)
+        near_ties = None
         try:
-            lf, tf_, hf = probe()              # also the warm-up of the f32 kernels
+            lf, tf_, hf, sf = probe()          # also the warm-up of the f32 kernels
+            try:
+                # patches whose two best NOISY assignment logits (log soft + Gumbel) are closer than the bound the B = 256 oracle test
+                # accepts for a flipped patch: the places where fp32 summation order alone may turn the 8-way argmax against the CPU
+                # reference ("bit-exact token indexing" holds everywhere else)
+                gmb = noise["gumbel_main"].float()
+                if sf is not None and sf.shape == gmb.shape:
+                    y = sf.clamp_min(1e-38).log() + gmb
+                    top2 = y.topk(2, dim=1).values
+                    near_ties = int(((top2[:, 0] - top2[:, 1]) <= 2e-4 * top2[:, 0].abs().clamp_min(1.0)).sum())
+            except Exception:
+                near_ties = None
+            del sf
             torch.cuda.synchronize()
             if multi:
                 dist.barrier()
@@ -482,7 +497,12 @@ def main():
             segclip_amd.set_compute_dtype(torch.bfloat16)
         parity_mode = {"dtype": "f32", "pairs_per_s": round(a.batch * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": 3,
                        "note": "exact-f32 mode (v_mfma_f32_32x32x2_f32 GEMMs, fp32 activations): the mode the parity tests hold to "
-                               "1e-3 / bit-exact indices against the reference; same model, same batch"}
+                               "1e-3 / bit-exact indices against the reference; same model, same batch",
+                       "hard_idx_near_ties_b256": near_ties, "hard_idx_patches": int(hf.numel()),
+                       "hard_idx_note": "patches of this batch whose two best noisy assignment logits differ by <= 2e-4 (relative) in the "
+                                        "exact-f32 run: only there may the 8-way argmax differ from the CPU reference by fp32 summation "
+                                        "order (tests/test_bench_size_gpu.py::test_b256_exact_f32_against_cpu_oracle: every differing "
+                                        "patch must be such a near-tie, at most 5; measured 1 of 50176)"}
         bf16_vs_f32 = {"d_loss": round(abs(lb - lf), 6), "max_dlogit": round(float((tb - tf_).abs().max()), 4),
                        "hard_idx_agree": round(float((hb == hf).float().mean()), 5),
                        "note": "benchmarked bf16 mode against the exact-f32 mode, same batch and injected Gumbel noise; bf16 does not "

@@ -190,11 +190,12 @@ def test_b256_bf16_t18_mode_the_bench_runs_against_exact_f32_mode():
           f"(ratio {ratios[cm]:.3f}), worst vector {cv} {cos[cv]:.4f}")
     assert dl <= 2e-3 and dlog <= 0.8 and agree >= 0.985, (dl, dlog, agree)
     assert float(np.median(list(cos.values()))) >= 0.95
-    # floors = the measured minima (profiles/r04_accuracy_b256.txt: matrices 0.716, vectors 0.57) minus 10 %
+    # floors = the measured minima (profiles/r05_accuracy_b256.txt, "t18": matrices 0.9125 / ratio 0.986-1.097, vectors 0.868 /
+    # ratio 0.91-1.12) minus ~10 % (the r4 floors 0.64 / 0.51 were far below what is measured)
     for n in mats:
-        assert cos[n] >= 0.64 and 0.75 <= ratios[n] <= 1.15, (n, cos[n], ratios[n])
+        assert cos[n] >= 0.82 and 0.85 <= ratios[n] <= 1.20, (n, cos[n], ratios[n])
     for n in vecs:
-        assert cos[n] >= 0.51 and 0.45 <= ratios[n] <= 1.6, (n, cos[n], ratios[n])
+        assert cos[n] >= 0.78 and 0.75 <= ratios[n] <= 1.30, (n, cos[n], ratios[n])
 
 
 def test_b256_full_loss_bf16_against_exact_f32_mode():
@@ -289,6 +290,68 @@ def test_b256_exact_f32_against_cpu_oracle(flags):
         assert torch.equal(got["ids_restore"], aux["ids_restore"].long())      # the MAE shuffle: integer function of the noise
         mm = (got["mae_hard_idx"] != aux["mae_hard_idx"]).nonzero()
         assert mm.shape[0] <= 5, mm.shape[0]
+
+
+def test_b32_gradients_against_cpu_oracle():
+    """GRADIENTS above B = 5 against the oracle (VERDICT r5 weak #1c: the B = 256 tests hold the forward to the oracle and the
+    gradients only to the HIP f32 mode).  ViT-B/16, B = 32, full loss, "t18" mode: 6272 vision token rows = 24 full 256-row tiles +
+    a 128-row remainder, i.e. the multi-tile forward / data-gradient kernels with their half-tile rows, the split-K and grouped weight
+    gradients and the streaming attention backward that the B <= 5 tests never reach.  (i) HIP exact-f32: loss, logits, every index
+    map and EVERY parameter gradient against `oracle.segclip_forward(...).backward()` on the same seeded inputs, bound as at B = 5
+    (max |d| <= 5e-3 max |ref|); (ii) the bf16 mode of the same batch against those ORACLE gradients by cosine and norm ratio."""
+    from oracle import segclip_oracle as so
+    from tests.helpers import model_param_shapes, oracle_params
+    spec = synth.SPECS["vitb16"]
+    B, seed = 32, 5
+    f = _run("vitb16", B, seed, torch.float32, FULL_FLAGS, "t18", keep_grads=True)
+    P = oracle_params(spec, model_param_shapes(spec, FULL_FLAGS))
+    lo, aux = so.segclip_forward(synth.synthetic_batch(spec, B, seed=seed, with_seg=True), P, spec,
+                                 synth.synthetic_noise(spec, B, seed=seed), FULL_FLAGS, cross_mode="t18")
+    lo.backward()
+    ref = {n: P[n].grad for n in P if P[n].grad is not None}
+    lo_f = float(lo.detach())
+    assert abs(f["loss"] - lo_f) <= 1e-3, (f["loss"], lo_f)
+    assert torch.equal(f["hard_idx"].long(), aux["hard_idx"]), "8-way hard assignment differs from the oracle at B = 32"
+    assert torch.equal(f["ids_restore"].long(), aux["ids_restore"].long())
+    assert float((f["t2v"] - aux["t2v"].detach()).abs().max()) <= 1e-3
+    worst, wn = 0.0, None
+    for n, g in f["grads"].items():
+        assert n in ref, n
+        r = ref[n]
+        err = float((g.cpu() - r).abs().max())
+        rel = err / (float(r.abs().max()) + 1e-12)
+        if rel > worst:
+            worst, wn = rel, n
+        assert err <= 5e-3 * float(r.abs().max()) + 1e-6, (n, err, float(r.abs().max()))
+    assert set(ref) <= set(f["grads"]) | {n for n in ref if float(ref[n].abs().max()) == 0.0}
+    print(f"\n[B=32 f32 vs oracle, full loss] loss {f['loss']:.6f} vs {float(lo):.6f}; {len(f['grads'])} parameter gradients, "
+          f"worst max|d| / max|ref| {worst:.2e} ({wn})")
+    b = _run("vitb16", B, seed, torch.bfloat16, FULL_FLAGS, "t18", keep_grads=True)
+    cos, rat = {}, {}
+    for n, g in b["grads"].items():
+        r = ref[n].double()
+        rn = float(r.norm())
+        if rn <= 1e-9:
+            continue
+        gd = g.cpu().double()
+        cos[n] = float((gd * r).sum()) / (float(gd.norm()) * rn + 1e-30)
+        rat[n] = float(gd.norm()) / rn
+    mats = [n for n in cos if b["dim"][n] >= 2]
+    vecs = [n for n in cos if b["dim"][n] < 2]
+    cm, cv = min(mats, key=lambda n: cos[n]), min(vecs, key=lambda n: cos[n])
+    agree = float((b["hard_idx"].long() == aux["hard_idx"]).float().mean())
+    print(f"[B=32 bf16 vs ORACLE gradients] loss {b['loss']:.5f} vs {float(lo):.5f}; hard_idx agreement {agree:.4f}; cosine median "
+          f"{float(np.median(list(cos.values()))):.4f}, worst matrix {cm} {cos[cm]:.4f} (ratio {rat[cm]:.3f}), worst vector {cv} "
+          f"{cos[cv]:.4f} (ratio {rat[cv]:.3f}); norm ratio {min(rat.values()):.3f} .. {max(rat.values()):.3f}")
+    assert abs(b["loss"] - float(lo)) <= 5e-3
+    assert agree >= 0.98, agree
+    assert float(np.median(list(cos.values()))) >= 0.97
+    # floors: the minima measured on MI355X (round 6: worst matrix layers0.2.attn.out_proj.weight cosine 0.8752, worst vector
+    # layers0.1.ln_1.bias 0.8584, norm ratio 0.932 .. 1.214, hard_idx agreement 0.9936, f32 gradients 4.9e-5 of max |ref|) minus ~10 %
+    for n in mats:
+        assert cos[n] >= 0.79 and 0.84 <= rat[n] <= 1.33, (n, cos[n], rat[n])
+    for n in vecs:
+        assert cos[n] >= 0.77 and 0.84 <= rat[n] <= 1.33, (n, cos[n], rat[n])
 
 
 def test_b4_bf16_grad_norms_against_reference_golden():
