@@ -617,7 +617,6 @@ __global__ __launch_bounds__(512) void attn_bwd_bf16_kernel(BwdArgs a) {
 #include "attention_pf.inc"
 #include "attention_spl.inc"
 #include "attention_dqw.inc"
-#include "attention_sq.inc"
 #include "attention_stream.inc"
 // e4m3 forward (BASELINE configs[4] as first read): forward-only, non-scaled e4m3 MFMA = the bf16 rate, measured SLOWER than the
 // bf16 kernel in every round (1350 vs 1395 pairs/s at B = 128, profiles/r04_bench_configs.json).  Round 5: out of the default
@@ -922,22 +921,6 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
         return launch_bwd_dqw<7>(a, ncu, dev, stream);
       // vision tower (no mask, 5-7 tiles): the variant whose memory traffic is issued by a loader wave (attention_spl.inc);
       // SEGCLIP_ATTN_BWD_SPL=0 keeps attention_sp.inc
-      // attention_sq.inc: the query tiles as a stream (round 5; SEGCLIP_ATTN_BWD_SQ=1)
-      static const int use_sq = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_SQ"); return e ? atoi(e) : 0; }();
-      if (use_sq && !masked && tiles >= 5 && tiles <= 7 && bwd_sq_lds_bytes((int)d->Tq) <= 160 * 1024) {
-        static bool sq_attr_set[64] = {};
-        if (!sq_attr_set[dev]) {
-          hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sq_bf16_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          SEGCLIP_REQUIRE(e3 == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e3));
-          sq_attr_set[dev] = true;
-        }
-        int64_t g2 = grid_env == 0 ? a.nitems : (int64_t)ncu * (grid_env > 0 ? grid_env : 1);
-        if (g2 > a.nitems) g2 = a.nitems;
-        hipLaunchKernelGGL(attn_bwd_sq_bf16_kernel, dim3((unsigned)g2), dim3((tiles + 1) * 64), bwd_sq_lds_bytes((int)d->Tq), stream, a);
-        SEGCLIP_CHECK_LAUNCH("attn_bwd_sq_bf16");
-        return 0;
-      }
       static const int use_spl = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_SPL"); return e ? atoi(e) : 1; }();
       if (use_spl && !masked && tiles >= 5 && tiles <= 7 && bwd_spl_lds_bytes((int)d->Tq) <= 160 * 1024) {
         static bool spl_attr_set[64] = {};
