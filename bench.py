@@ -493,6 +493,32 @@ def main():
             if multi:
                 dist.barrier()
             dt = (time.perf_counter() - t1) / 3
+            # ... and the same mode with the Linear layers as bf16 x 3 products on the bf16 matrix pipe (config.f32_split), held to the
+            # same parity bounds by the tests: timed, and compared with the exact run above on the same batch and noise
+            parity_split = None
+            try:
+                segclip_amd.config.f32_split = True
+                ls, ts_, hs, _ = probe()
+                torch.cuda.synchronize()
+                if multi:
+                    dist.barrier()
+                t2 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                if multi:
+                    dist.barrier()
+                dts = (time.perf_counter() - t2) / 3
+                parity_split = {"dtype": "f32, Linear layers as A_hi B_hi + A_lo B_hi + A_hi B_lo on the bf16 matrix pipe (config.f32_split)",
+                                "pairs_per_s": round(a.batch * world / dts, 1), "ms_per_step": round(dts * 1e3, 2), "steps": 3,
+                                "vs_exact_f32": {"d_loss": round(abs(ls - lf), 7), "max_dlogit": round(float((ts_ - tf_).abs().max()), 6),
+                                                 "hard_idx_differ": int((hs != hf).sum())},
+                                "note": "tests/test_bench_size_gpu.py::test_b256_exact_f32_against_cpu_oracle[f32_split] and "
+                                        "tests/test_model_gpu.py::test_vitb16_b4_f32_split_matches_reference_golden hold this mode to the "
+                                        "same 1e-3 / index bounds as the exact one"}
+                del ts_, hs
+            finally:
+                segclip_amd.config.f32_split = False
         finally:
             segclip_amd.set_compute_dtype(torch.bfloat16)
         parity_mode = {"dtype": "f32", "pairs_per_s": round(a.batch * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": 3,
@@ -502,7 +528,8 @@ def main():
                        "hard_idx_note": "patches of this batch whose two best noisy assignment logits differ by <= 2e-4 (relative) in the "
                                         "exact-f32 run: only there may the 8-way argmax differ from the CPU reference by fp32 summation "
                                         "order (tests/test_bench_size_gpu.py::test_b256_exact_f32_against_cpu_oracle: every differing "
-                                        "patch must be such a near-tie, at most 5; measured 1 of 50176)"}
+                                        "patch must be such a near-tie, at most 5; measured 1 of 50176)",
+                       "f32_split": parity_split}
         bf16_vs_f32 = {"d_loss": round(abs(lb - lf), 6), "max_dlogit": round(float((tb - tf_).abs().max()), 4),
                        "hard_idx_agree": round(float((hb == hf).float().mean()), 5),
                        "note": "benchmarked bf16 mode against the exact-f32 mode, same batch and injected Gumbel noise; bf16 does not "

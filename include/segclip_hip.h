@@ -233,6 +233,11 @@ int segclip_attn_bwd(const segclip_attn_desc* d, void* stream);
  * ------------------------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i] */
 int segclip_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* fp32 operand -> its two bf16 parts, three blocks along the contraction dimension (role 0: hi|lo|hi, role 1: hi|hi|lo; stack 0:
+ * blocks side by side in a row of 3*cols, stack 1: three (rows x cols) blocks one after the other).  With both operands split this
+ * way ONE bf16 GEMM of contraction length 3K computes A_hi B_hi + A_lo B_hi + A_hi B_lo in fp32 accumulators: the fp32 parity mode
+ * of the Linear layers (reference arithmetic: main_task_align.py:102, fp32 torch.nn.Linear) on the bf16 matrix pipe. */
+int segclip_split3_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int stack, int role, void* stream);
 /* out[n] = sum_m X[m*ld + n]  (bias gradients; deterministic two-stage).  ws: colsum_ws_bytes */
 size_t segclip_colsum_ws_bytes(int64_t M, int64_t N);
 int segclip_colsum(const void* X, float* out, void* ws, int64_t M, int64_t N, int64_t ld, int dtype,

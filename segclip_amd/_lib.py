@@ -95,6 +95,7 @@ SIGNATURES = {
     "segclip_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "segclip_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "segclip_cast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "segclip_split3_bf16": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
     "segclip_colsum_ws_bytes": (C.c_size_t, [i64, i64]),
     "segclip_colsum": (C.c_int, [vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "segclip_act_fwd": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),

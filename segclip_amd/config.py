@@ -70,6 +70,11 @@ pad_rows      : bf16 mode, inside ResStackFn: a stack whose token-row count B x 
                 Pad rows start as zeros and carry zero gradients; results for the token rows are those of the unpadded stack.
                 Applies from 6144 token rows on (below, the step is host-bound and the extra small launches cost more).  Measured
                 per-GPU batch 96: 5252 -> 5859 pairs/s, 160: 5975 -> 6457 (same box)
+f32_split     : exact-f32 mode only.  False (default): Linear layers on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, an
+                exact fmaf chain: 1/16 of the bf16 rate).  True: every large fp32 GEMM runs as ONE bf16 GEMM of three times the
+                contraction length over the operands' (hi, lo) bf16 parts - A_hi B_hi + A_lo B_hi + A_hi B_lo, fp32 accumulation,
+                ~2^-16 relative per product instead of 2^-24 - on the bf16 matrix pipe; assignment logits, contrastive logits and the
+                attention core stay exact fp32.  Held to the same 1e-3 / index bounds as the exact mode by the parity tests.
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -100,7 +105,7 @@ def tuning_env(name, default):
     return v
 
 
-_DEFAULTS = dict(compute_dtype=torch.float32, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
+_DEFAULTS = dict(compute_dtype=torch.float32, f32_split=False, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=tuning_env("SEGCLIP_AUX_U8", "1") != "0",
                  text_after_blocks=3, text_trim=False, text_trim_hint=None, pad_rows=tuning_env("SEGCLIP_PAD_ROWS", "1") != "0", fold_param_grads=tuning_env("SEGCLIP_FOLD_GRADS", "1") != "0",

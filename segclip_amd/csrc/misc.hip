@@ -653,9 +653,45 @@ __global__ void mask_sort_kernel(const float* __restrict__ noise, int64_t* __res
   }
 }
 
+// fp32 -> two bf16 parts (hi = rne(x), lo = rne(x - hi): 16 mantissa bits together), written three times along the CONTRACTION
+// dimension of a GEMM operand: role 0 (A) = hi | lo | hi, role 1 (B) = hi | hi | lo, so that ONE bf16 GEMM of contraction length
+// 3 K sums A_hi B_hi + A_lo B_hi + A_hi B_lo in its fp32 accumulators (config.f32_split: the parity mode on the bf16 matrix pipe).
+// stack = 0: the contraction runs along the row (dst row pitch 3 * cols, blocks side by side); stack = 1: along the rows (dst =
+// three (rows x cols) blocks one after the other).  4 elements per thread.
+__global__ void split3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int64_t cols, int64_t ld,
+                              int stack, int role) {
+  const int64_t c4 = cols >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4) return;
+  const int64_t r = i / c4, c = (i - r * c4) << 2;
+  const f32x4 x = *reinterpret_cast<const f32x4*>(src + r * ld + c);
+  u32x2 hi, lo;
+  float h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { h[j] = bf2f(f2bf(x[j])); l[j] = x[j] - h[j]; }
+  hi[0] = pack2bf(h[0], h[1]); hi[1] = pack2bf(h[2], h[3]);
+  lo[0] = pack2bf(l[0], l[1]); lo[1] = pack2bf(l[2], l[3]);
+  const int64_t pitch = stack ? cols : 3 * cols, blk = stack ? rows * cols : cols;
+  bf16_t* d = dst + r * pitch + c;
+  *reinterpret_cast<u32x2*>(d) = hi;
+  *reinterpret_cast<u32x2*>(d + blk) = role == 0 ? lo : hi;
+  *reinterpret_cast<u32x2*>(d + 2 * blk) = role == 0 ? hi : lo;
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int segclip_split3_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int stack, int role,
+                                   void* stream) {
+  SEGCLIP_REQUIRE(cols % 4 == 0 && ld % 4 == 0, "split3: cols and ld must be multiples of 4");
+  SEGCLIP_REQUIRE((role == 0 || role == 1) && (stack == 0 || stack == 1), "split3: role / stack must be 0 or 1");
+  if (rows == 0 || cols == 0) return 0;
+  const int64_t n = rows * (cols >> 2);
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ST, src, (bf16_t*)dst, rows, cols, ld, stack, role);
+  SEGCLIP_CHECK_LAUNCH("split3");
+  return 0;
+}
 
 extern "C" int segclip_cast(const void* src, void* dst, int64_t n, int sd, int dd, void* stream) {
   if (n == 0) return 0;

@@ -238,6 +238,12 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
     r_mod > 0: the residual of output row m is residual row m % r_mod (L.Unsupported where the library has no such kernel)."""
     lib = L.load()
     L.require_cuda(A, B, Cc)
+    if (A.dtype == torch.float32 and B.dtype == torch.float32 and Cc.dtype == torch.float32 and nb1 * nb2 == 1 and colsum is None
+            and r_mod == 0 and M >= 256 and N >= 64 and K >= 64 and K % 8 == 0):
+        from . import config as _cfg
+        if _cfg.f32_split and _gemm_f32_split(A, B, Cc, M, N, K, sa, sb, ldc, a_off, b_off, c_off, bias, residual, ldr, r_off, aux,
+                                              ldaux, act, mul_dact, alpha, aux_kind, defer):
+            return Cc
     d = L.GemmDesc()
     d.A, d.B, d.C = _off(A, a_off), _off(B, b_off), _off(Cc, c_off)
     d.bias = L.ptr(bias)
@@ -300,6 +306,42 @@ def p_gemm(A, B, Cc, M, N, K, sa, sb, ldc, *, a_off=0, b_off=0, c_off=0, bias=No
         return Cc
     L.check(lib.segclip_gemm(C.byref(d), L.stream()), "gemm")
     return Cc
+
+
+def _split3(t, off, rows, cols, ld, stack, role):
+    """fp32 operand (rows x cols view at element offset `off`, row pitch ld) -> its (hi, lo) bf16 parts, three blocks along the
+    contraction dimension (include/segclip_hip.h: segclip_split3_bf16)."""
+    out = torch.empty((3 * rows, cols) if stack else (rows, 3 * cols), dtype=torch.bfloat16, device=t.device)
+    L.check(L.load().segclip_split3_bf16(_off(t, off), L.ptr(out), rows, cols, ld, int(stack), int(role), L.stream()), "split3")
+    return out
+
+
+def _gemm_f32_split(A, B, Cc, M, N, K, sa, sb, ldc, a_off, b_off, c_off, bias, residual, ldr, r_off, aux, ldaux, act, mul_dact,
+                    alpha, aux_kind, defer):
+    """config.f32_split: C = epi(A B^T) for fp32 operands as ONE bf16 GEMM of contraction length 3 K over the operands' bf16 parts
+    (A: hi | lo | hi, B: hi | hi | lo along k: A_hi B_hi + A_lo B_hi + A_hi B_lo, fp32 accumulators and epilogue).  Returns False
+    when a layout or an epilogue has no bf16 kernel: the caller then takes the exact fp32 GEMM."""
+    (sam, sak), (sbn, sbk) = sa, sb
+    if not ((sak == 1 or sam == 1) and (sbk == 1 or sbn == 1)):
+        return False
+    if (sak == 1 and (sam % 4 or K % 4)) or (sak != 1 and (sak % 4 or M % 4)) or (sbk == 1 and (sbn % 4 or K % 4)) or (sbk != 1 and (sbk % 4 or N % 4)):
+        return False
+    if a_off % 4 or b_off % 4:
+        return False
+    if sak == 1:      # A stored (M, K): blocks side by side
+        A3, sa3 = _split3(A, a_off, M, K, sam, False, 0), (3 * K, 1)
+    else:             # A stored (K, M), k-strided: blocks stacked along k
+        A3, sa3 = _split3(A, a_off, K, M, sak, True, 0), (1, M)
+    if sbk == 1:
+        B3, sb3 = _split3(B, b_off, N, K, sbn, False, 1), (3 * K, 1)
+    else:
+        B3, sb3 = _split3(B, b_off, K, N, sbk, True, 1), (1, N)
+    try:
+        p_gemm(A3, B3, Cc, M, N, 3 * K, sa3, sb3, ldc, c_off=c_off, bias=bias, residual=residual, ldr=ldr, r_off=r_off, aux=aux,
+               ldaux=ldaux, act=act, mul_dact=mul_dact, alpha=alpha, aux_kind=aux_kind, defer=defer)
+    except L.Unsupported:
+        return False
+    return True
 
 
 def _ld(x):
@@ -1077,7 +1119,7 @@ class ResBlockFn(Function):
         ctx.overlap_wgrad = bool(_cfg.overlap_wgrad)
         ctx.gslots = tuple(_slot_of(w) for w in (wqkv, wo, wfc, wpr))
         ctx.vslots = tuple(_slot_of(w) for w in (ln1w, ln1b, bqkv, bo, ln2w, ln2b, bfc, bpr))
-        _GradFold.other.add(id(ln1w))                        # a producer that does not fold: its block's gradients go the engine's way
+        _GradFold.other[id(ln1w)] = weakref.ref(ln1w)        # a producer that does not fold: its block's gradients go the engine's way
         return xo.view(B, T, D)
 
     @staticmethod
@@ -1107,7 +1149,7 @@ class _GradFold:
     armed = -1
     first = {}
     uses = {}      # id(first parameter of a block) -> ResStackFn forwards over that block since the last advance(): armed from 2
-    other = set()  # id(first parameter of a block) that a NON-stack node (ResBlockFn) used since the last advance(): never folded.
+    other = {}     # id(first parameter of a block) -> weak reference to it, for blocks a NON-stack node (ResBlockFn) used since the last advance(): never folded.
     #                Folding is only sound while every producer of a parameter's gradient in the pass is a folding ResStackFn node: a
     #                gradient delivered by another producer in between makes the engine build a NEW sum tensor (the alias below raises
     #                the storage's use count), and a later in-place add would land in the stale one
@@ -1118,6 +1160,11 @@ class _GradFold:
         cls.first.clear()
         cls.uses.clear()
         cls.other.clear()
+
+    @classmethod
+    def used_elsewhere(cls, p):
+        r = cls.other.get(id(p))
+        return r is not None and r() is p      # (an id alone may be a dead tensor's, reused)
 
     @classmethod
     def take(cls, p, gr, adds):
@@ -1276,7 +1323,7 @@ class ResStackFn(Function):
                     grq.flush()
                 left = sizes.pop(0) if sizes else nblk
             for b_, P_, sl_, grads_ in pending:
-                fold = ctx.fold and _GradFold.uses.get(id(P_[0]), 0) > 1 and id(P_[0]) not in _GradFold.other   # only blocks a second STACK node of this pass shares
+                fold = ctx.fold and _GradFold.uses.get(id(P_[0]), 0) > 1 and not _GradFold.used_elsewhere(P_[0])   # only blocks a second STACK node of this pass shares
                 for i, (p, gr, slot) in enumerate(zip(P_, grads_, sl_)):
                     if gr is None:
                         continue

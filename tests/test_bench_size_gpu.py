@@ -221,8 +221,9 @@ def test_b256_full_loss_bf16_against_exact_f32_mode():
         assert lo <= ratios[n] <= hi and cos[n] >= cmin, (n, ratios[n], cos[n])
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["exact", "f32_split"])
 @pytest.mark.parametrize("flags", [{}, FULL_FLAGS], ids=["contrastive", "full_loss"])
-def test_b256_exact_f32_against_cpu_oracle(flags):
+def test_b256_exact_f32_against_cpu_oracle(flags, split):
     """The benchmarked SIZE against the oracle itself (the B = 256 tests above compare the HIP bf16 mode
     with the HIP f32 mode - a self-comparison).  HIP exact-f32 mode, "t18" cross-attention (what bench.py times), ViT-B/16,
     B = 256, contrastive-only (BASELINE configs[1]) and full loss (configs[3]) against oracle.segclip_forward on the same
@@ -235,6 +236,7 @@ def test_b256_exact_f32_against_cpu_oracle(flags):
     B, seed = 256, 3
     segclip_amd.set_compute_dtype(torch.float32)
     segclip_amd.set_cross_mode("t18")
+    segclip_amd.config.f32_split = split     # the same bounds for the Linear layers as bf16 x 3 products (config.f32_split)
     try:
         model, _ = synth.build_model(spec, flags, device=DEV)
         batch = synth.synthetic_batch(spec, B, seed=seed, device=DEV, with_seg=bool(flags))
@@ -252,6 +254,7 @@ def test_b256_exact_f32_against_cpu_oracle(flags):
         del model, loss
         torch.cuda.empty_cache()
     finally:
+        segclip_amd.config.f32_split = False
         segclip_amd.set_compute_dtype(torch.float32)
         segclip_amd.set_cross_mode("t18")
     P = oracle_params(spec, model_param_shapes(spec, flags), requires_grad=False)
@@ -264,7 +267,7 @@ def test_b256_exact_f32_against_cpu_oracle(flags):
     d2 = float((got["v2t"] - aux["v2t"]).abs().max())
     mism = (got["hard_idx"] != aux["hard_idx"]).nonzero()
     agree = 1.0 - mism.shape[0] / got["hard_idx"].numel()
-    print(f"\n[B=256 f32 vs oracle, {'full loss' if flags else 'contrastive'}] loss {got['loss']:.6f} vs {float(lo):.6f} (d {dl:.2e}); "
+    print(f"\n[B=256 f32{' (f32_split)' if split else ''} vs oracle, {'full loss' if flags else 'contrastive'}] loss {got['loss']:.6f} vs {float(lo):.6f} (d {dl:.2e}); "
           f"max |d t2v| {d1:.2e}, |d v2t| {d2:.2e} ({float((dt <= 1e-3).float().mean()):.5f} of the logits within 1e-3); "
           f"hard_idx: {mism.shape[0]} of {got['hard_idx'].numel()} patches differ (agreement {agree:.6f})")
     assert dl <= 1e-3, dl

@@ -7,6 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import segclip_amd  # noqa: E402
 from segclip_amd import ops  # noqa: E402
 
 DEV = "cuda"
@@ -308,6 +309,35 @@ def test_layernorm_bwd_pipelined_variants(rows, cols, resdt):
         close(out[-1], dres.float().sum(0), 1e-5, 1e-3 * rows ** 0.5, "colsum(dres)")
     close(out[1], wr.grad, 1e-4, 1e-3 * rows ** 0.5, "ln dgamma")
     close(out[2], br.grad, 1e-4, 1e-3 * rows ** 0.5, "ln dbeta")
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (3136, 2304, 768), (1024, 768, 3072)])
+def test_gemm_f32_split_against_fp64(M, N, K):
+    """config.f32_split: fp32 Linear forward / data gradient / weight gradient as ONE bf16 GEMM over the operands' (hi, lo) parts
+    (segclip_split3_bf16) against an fp64 product of the same fp32 operands, next to the exact fp32 GEMM: the split form must stay
+    within 2e-5 of the product's scale (measured 3-5e-6 - the exact fp32 GEMM: 1-2.4e-6, both dominated by the fp32 accumulation;
+    bf16 alone: 4e-3)."""
+    x = rnd(M, K, dtype=F32, seed=61)
+    w = rnd(N, K, dtype=F32, seed=62) * (K ** -0.5)
+    b = rnd(N, dtype=F32, seed=63)
+    dy = rnd(M, N, dtype=F32, seed=64)
+    ref_y = (x.double() @ w.double().t() + b.double())
+    ref_dx = dy.double() @ w.double()
+    ref_dw = dy.double().t() @ x.double()
+    errs = {}
+    for split in (False, True):
+        segclip_amd.config.f32_split = split
+        try:
+            y, _ = ops.p_linear(x, w, b)
+            dx = ops.p_dgrad(dy, w, F32)
+            dw = ops.p_wgrad(dy, x)
+        finally:
+            segclip_amd.config.f32_split = False
+        errs[split] = tuple(float((got.double() - ref).abs().max() / ref.abs().max()) for got, ref in ((y, ref_y), (dx, ref_dx), (dw, ref_dw)))
+    print(f"\n[f32 GEMM M={M} N={N} K={K}] max |d| / max |ref|: exact {errs[False]}, bf16 x 3 {errs[True]}")
+    assert max(errs[False]) <= 5e-6, errs
+    assert max(errs[True]) <= 2e-5, errs
+    assert errs[True] != errs[False], "the split path was not taken"
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -80,6 +80,20 @@ def test_vitb16_b4_f32_matches_reference_golden():
     check_against_golden(model, loss, g, 1e-3, 1e-3, 2e-2)
 
 
+def test_vitb16_b4_f32_split_matches_reference_golden():
+    """The same golden, exact-f32 mode with config.f32_split (Linear layers as bf16 x 3 products on the bf16 matrix pipe): the SAME
+    bounds as the exact mode - loss and logits 1e-3, index maps exact, gradient norms."""
+    g = load_golden("vitb16_b4_t18.npz")
+    segclip_amd.config.f32_split = True
+    try:
+        model, loss = run_model("vitb16", int(g["B"]), int(g["seed"]), "t18", torch.float32)
+    finally:
+        segclip_amd.config.f32_split = False
+    print(f"\n[f32_split vitb16 B=4] loss {float(loss):.6f} vs ref {float(g['loss']):.6f}; max |dlogit| "
+          f"{float((model.last_logits[0].cpu() - torch.from_numpy(g['t2v'])).abs().max()):.2e}")
+    check_against_golden(model, loss, g, 1e-3, 1e-3, 2e-2)
+
+
 def test_tiny_f32_matches_cpu_oracle_fresh_seed():
     """Same seeded inputs through the HIP path and the CPU oracle (not a stored fixture)."""
     from oracle import segclip_oracle as so
