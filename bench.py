@@ -63,6 +63,7 @@ def parse():
                          "configs[4], profiles/r03_bench_configs.json); `on` keeps the configs[4] switch reachable")
     ap.add_argument("--resid", default="auto", choices=["auto", "bf16", "fp32"],
                     help="residual stream between the blocks of a tower in bf16 mode (config.bf16_resid); auto = the package default")
+    ap.add_argument("--f32-split", action="store_true", help="with --dtype f32: config.f32_split (Linear layers as bf16 x 3 products)")
     ap.add_argument("--text-trim", action="store_true",
                     help="config.text_trim for the TIMED region (opt-in, off by default: the headline times the reference's full "
                          "77-token context): the causal text tower on the positions up to the batch's last EOT only - identical loss "
@@ -372,6 +373,8 @@ def main():
     spec = synth.SPECS[a.spec]
     flags = dict(use_seglabel=True, use_vision_mae_recon=True) if a.full_loss else {}
     segclip_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    if a.f32_split:
+        segclip_amd.config.f32_split = True
     attn_fp8 = a.dtype == "bf16" and a.attn_fp8 == "on"
     segclip_amd.config.attn_fp8 = attn_fp8
     if a.resid != "auto":

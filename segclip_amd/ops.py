@@ -1525,19 +1525,27 @@ class CrossBlockFn(Function):
             g = p_cast(g, torch.float32)
         g16 = p_cast(g, act_dtype) if bf else g
         rq = ReduceQueue()
+        # the four weight gradients over the block's 8 center rows per sample (B*G rows: 9-36 output tiles each, 42 us apiece as
+        # separate split-K launches) run as ONE grouped launch at the end of the node (round 6; bf16 mode)
+        wg = WgradGroup() if (bf and _CROSS_WGRAD_GROUP) else None
+
+        def small_wgrad(dy_, x_, out_):
+            if wg is not None and WgradGroup.covers(dy_, x_, out_):
+                return wg.add(dy_, x_, out=out_)
+            return p_wgrad(dy_, x_, out=out_, defer=rq)
         # ---- MLP
         du, dbfc = p_dgrad(g16, wpr_c, act_dtype, aux=u, act=act, want_colsum=True,
                            aux_kind=2 if u.dtype == torch.uint8 else _aux_kind(act_dtype, act), defer=rq)
-        dwpr = p_wgrad(g16, h, out=_slot_out(s_pr, (D, F4)), defer=rq)
+        dwpr = small_wgrad(g16, h, _slot_out(s_pr, (D, F4)))
         dz = p_dgrad(du, wfc_c, act_dtype)
-        dwfc = p_wgrad(du, z, out=_slot_out(s_fc, (F4, D)), defer=rq)
+        dwfc = small_wgrad(du, z, _slot_out(s_fc, (F4, D)))
         r = p_ln_bwd(dz, q1, ln2w, m2, r2, dres=g, dx_dtype=torch.float32, want_bf16=bf, want_dres_colsum=True, defer=rq)
         dq1, dln2w, dln2b = r[0], r[1], r[2]
         dq1_16 = r[3] if bf else dq1
         dbpr = r[-1]                                             # colsum(g): the c_proj bias gradient
         # ---- attention
         do = p_dgrad(dq1_16, wo_c, act_dtype)
-        dwo = p_wgrad(dq1_16, o, out=_slot_out(s_o, (D, D)), defer=rq)
+        dwo = small_wgrad(dq1_16, o, _slot_out(s_o, (D, D)))
         ks = (2 * D, B * 2 * D) if mode == "t18" else (S * 2 * D, 2 * D)
         ad = _attn_desc(qp, kv, kv, o, B, n_head, G, S, hd, (G * D, D), ks, ks, (G * D, D), 1.0 / math.sqrt(hd), False, 0, 0, D)
         dqp, dkv = torch.empty_like(qp), torch.empty_like(kv)
@@ -1548,7 +1556,7 @@ class CrossBlockFn(Function):
         dw_in = _slot_out(s_in, (3 * D, D))
         if dw_in is None:
             dw_in = _empty((3 * D, D), torch.float32, do)
-        p_wgrad(dqp, qn, out=dw_in[:D], defer=rq)
+        small_wgrad(dqp, qn, dw_in[:D])
         p_wgrad(dkv, kn2d, out=dw_in[D:], defer=rq)
         db_in = _empty((3 * D,), torch.float32, do)
         if part is not None:
@@ -1562,6 +1570,8 @@ class CrossBlockFn(Function):
         dq_a, dlnxw, dlnxb, dbo = r[0], r[1], r[2], r[-1]
         r = p_ln_bwd(dkn, q2d, lnkw, mk, rk, dres=dq_a, dx_dtype=torch.float32, defer=rq, seg=(G, S, 0))
         dq, dlnkw, dlnkb = r[0], r[1], r[2]
+        if wg is not None:
+            wg.flush()
         rq.flush()
         return (dq.view(B, G, D), dkn.view(B, S, D), dlnxw, dlnxb, dlnkw, dlnkb, dw_in, db_in, dwo, dbo, dln2w, dln2b, dwfc, dbfc,
                 dwpr, dbpr, None, None, None, None)
@@ -1691,6 +1701,7 @@ class ReconMixFn(Function):
 
 # config.pad_rows applies from this many token rows on: below it a step is bound by the host's launch rate (per-GPU batch 64:
 # 13.5 ms of enqueue per step), where the ~50 extra small launches of a padded tower cost more than the faster kernels return
+_CROSS_WGRAD_GROUP = _tenv("SEGCLIP_CROSS_WGRAD_GROUP", "1") != "0"   # A/B: 0 = the center blocks' weight gradients as separate launches
 _PAD_ROWS_MIN = int(_tenv("SEGCLIP_PAD_ROWS_MIN", "6144"))
 _RECON_MIX = _tenv("SEGCLIP_RECON_MIX", "1") != "0"      # A/B: 0 = the batched exact-fp32 GEMM
 
