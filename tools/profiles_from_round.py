@@ -90,13 +90,13 @@ for mode, (desc, M, N, K) in shapes.items():
                 f"L2 hit {k['TCC_HIT_sum'] / (k['TCC_HIT_sum'] + k['TCC_MISS_sum']):.3f}, HBM {hbm / 1e6:.0f} MB\n")
 open(P + "gemm_pmc.txt", "w").write(txt)
 open(P + "attn_pmc.txt", "w").write("# rocprofv3 --pmc passes on the attention kernels, B=256 T=196 H=12 hd=64 (tools/pmc_attn.sh); per launch.\n"
-                                   "# attn_bwd_sp_bf16_kernel = the single-pass backward (attention_sp.inc)\n" + open(R + "pmc_attn.txt").read())
+                                   "# attn_bwd_dqw_bf16_kernel = the streaming backward with a dQ wave (attention_dqw.inc, round 6)\n" + open(R + "pmc_attn.txt").read())
 for a, h in (("gemm_shapes.txt", "# GEMM rates per shape (tools/bench_gemm.py, HIP events, 10 launches each) next to torch.matmul (hipBLASLt) on the same MI355X.\n"),
              ("gemm_epilogues.txt", "# Fused-epilogue variants of one residual block's GEMMs against the plain kernel (tools/bench_epi.py, M = 50176, D = 768)\n"),
              ("gemm_pq.txt", "# gemm_bf16_pq.hip against the 8-phase kernel gemm_bf16_p8.hip per shape and mode, interleaved rounds (tools/bench_pq.py), M = 50176 (vision) and 19712 (text)\n"),
              ("hbm_kernels.txt", "# HBM-bound kernels against 8 TB/s (tools/bench_hbm.py)\n"),
              ("attn.txt", "# attention kernels in isolation (tools/bench_attn.py): T=196 vision (single-pass backward), T=77 causal text\n"),
-             ("center_stage.txt", "# Kernel time of the learnable-center stage alone (SemanticLearnerModule forward + backward, B = 256, bf16, t18 mode;\n# tools/debug/center_stage_profile.py, torch profiler, mean of 3 passes).  Round-3 build: 4.71 ms over 361 launches (DESIGN 4.5)\n"),
+             ("center_stage.txt", "# Kernel time of the learnable-center stage alone (SemanticLearnerModule forward + backward, B = 256, bf16, t18 mode;\n# tools/debug/center_stage_profile.py, torch profiler, mean of 3 passes).  Round-3 build: 4.71 ms over 361 launches, round 5: 3.18 ms over 241 (docs/experiment_log.md 4.5)\n"),
              ("stream_gaps.txt", "# tools/stream_gaps.py on the kernel trace of the bench child (profiled run: the host is slower than in the timed run)\n"),
              ("stream_breakdown.txt", "# tools/stream_breakdown.py on the same trace: kernel time per stream and kernel (the window holds more than the 3 passes it divides by:\n# read the rows relative to each other - stream 0 is the vision tower + everything serial, i.e. the critical path)\n"),
              ("gemm_half_tile.txt", "# tools/bench_pq_half.py: gemm_bf16_pq.hip with full tiles only against the half-tile tail (SEGCLIP_PQ_HALF=2, per-call switch), interleaved rounds, M = 50432; outputs bit-identical\n")):
