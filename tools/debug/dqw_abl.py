@@ -1,5 +1,5 @@
 """attention_dqw.inc at B = 256, T = 196 under SEGCLIP_ATTN_ABL (experiments library of tools/build_exp_attn.sh; results garbage for abl != 0):
-0 the kernel, 1 no memory instructions inside the step loop (compute only), 2 no compute (memory stream only)."""
+0 the kernel, 1 no memory instructions inside the step loop (compute only), 2 no compute (memory stream only), 11 / 12 / 13 s_setprio 1 for the dQ wave / key-owner waves 4-6 / all key-owners."""
 import sys, os, math, subprocess
 os.environ["SEGCLIP_TUNING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -23,5 +23,5 @@ if len(sys.argv) > 1:
     t = timeit(lambda: ops.p_attn_bwd(desc(), stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=cs))
     print(f"SEGCLIP_ATTN_ABL={sys.argv[1]}: {t * 1e6:.1f} us", flush=True)
 else:
-    for abl in sys.argv[2:] or ("0", "1", "2"):
+    for abl in sys.argv[2:] or ("0", "1", "2", "11", "12", "13", "0"):
         subprocess.run([sys.executable, __file__, abl], check=True)
