@@ -229,6 +229,35 @@ int segclip_attn_fwd(const segclip_attn_desc* d, void* stream);
 int segclip_attn_bwd(const segclip_attn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Launch executor: the forward of one pre-LN residual attention block (modules/module_seg_vit.py:175-196,
+ * modules/module_clip_ttransformer.py:20-37; bf16 mode) as ONE call - LayerNorm, in_proj, attention, out_proj + residual,
+ * LayerNorm, c_fc + activation + saved derivative, c_proj + residual: the seven launches the Python layer would issue, with the
+ * same descriptors, into caller-owned buffers (bit-identical results; what it saves is ~250 us of host time per block).
+ * x, x1, xo: the residual stream (M, D) in x_dtype (fp32, or bf16 with config.bf16_resid); everything else bf16 unless noted.
+ * M may exceed B*T (row-padded stack): the attention touches the B*T token rows, the pad rows of o are zeroed.
+ * Weights are the (out, in) bf16 copies of the reference's parameters; biases and LayerNorm affines fp32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct segclip_resblock_fwd_desc {
+  const void* x;                 /* (M, D) x_dtype */
+  const float* ln1w; const float* ln1b; const void* wqkv; const float* bqkv; const void* wo; const float* bo;
+  const float* ln2w; const float* ln2b; const void* wfc; const float* bfc; const void* wpr; const float* bpr;
+  void* y1; float* mean1; float* rstd1;   /* ln_1 output (M, D) and its row statistics */
+  void* qkv;                     /* (M, 3D) */
+  void* o;                       /* (M, D) attention output */
+  void* stats;                   /* segclip_attn_stats_bytes: the attention's softmax statistics */
+  void* x1;                      /* (M, D) x_dtype: the stream after the attention branch */
+  void* y2; float* mean2; float* rstd2;
+  void* h; int64_t ld_h;         /* (M, F) activation output, row pitch ld_h */
+  void* u; int64_t ld_u;         /* nullable: what the backward keeps of the pre-activation (aux_kind as in segclip_gemm_desc) */
+  void* xo;                      /* (M, D) x_dtype: the block's output */
+  const void* klen;              /* nullable: int32 [B] valid keys per sample */
+  int64_t M, B, T, D, F, H;
+  float eps, attn_scale;
+  int32_t causal, act, aux_kind, x_dtype;
+} segclip_resblock_fwd_desc;
+int segclip_resblock_fwd(const segclip_resblock_fwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Elementwise / reduction helpers
  * ------------------------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i] */

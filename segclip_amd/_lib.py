@@ -68,6 +68,15 @@ class AttnDesc(C.Structure):
                 ("scale", f32), ("causal", i32), ("dtype", i32), ("flags", i32), ("colsum_part", vp), ("klen", vp)]
 
 
+class ResBlockFwdDesc(C.Structure):
+    _fields_ = [("x", vp), ("ln1w", vp), ("ln1b", vp), ("wqkv", vp), ("bqkv", vp), ("wo", vp), ("bo", vp),
+                ("ln2w", vp), ("ln2b", vp), ("wfc", vp), ("bfc", vp), ("wpr", vp), ("bpr", vp),
+                ("y1", vp), ("mean1", vp), ("rstd1", vp), ("qkv", vp), ("o", vp), ("stats", vp), ("x1", vp),
+                ("y2", vp), ("mean2", vp), ("rstd2", vp), ("h", vp), ("ld_h", i64), ("u", vp), ("ld_u", i64), ("xo", vp),
+                ("klen", vp), ("M", i64), ("B", i64), ("T", i64), ("D", i64), ("F", i64), ("H", i64),
+                ("eps", f32), ("attn_scale", f32), ("causal", i32), ("act", i32), ("aux_kind", i32), ("x_dtype", i32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/segclip_hip.h
 SIGNATURES = {
     "segclip_version": (C.c_int, []),
@@ -94,6 +103,7 @@ SIGNATURES = {
     "segclip_attn_bwd_ws_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "segclip_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "segclip_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "segclip_resblock_fwd": (C.c_int, [C.POINTER(ResBlockFwdDesc), vp]),
     "segclip_cast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
     "segclip_split3_bf16": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
     "segclip_colsum_ws_bytes": (C.c_size_t, [i64, i64]),

@@ -75,6 +75,9 @@ f32_split     : exact-f32 mode only.  False (default): Linear layers on the fp32
                 contraction length over the operands' (hi, lo) bf16 parts - A_hi B_hi + A_lo B_hi + A_hi B_lo, fp32 accumulation,
                 ~2^-16 relative per product instead of 2^-24 - on the bf16 matrix pipe; assignment logits, contrastive logits and the
                 attention core stay exact fp32.  Held to the same 1e-3 / index bounds as the exact mode by the parity tests.
+c_exec        : bf16 mode: the forward launches of a residual block are enqueued by one C-ABI call (segclip_resblock_fwd) instead of
+                launch by launch through Python - bit-identical results, less host time (the step is host-bound below ~100 samples
+                per GPU).  Env SEGCLIP_C_EXEC=0 (with SEGCLIP_TUNING=1) for A/B.
 noise         : None -> draw Gumbel / uniform noise from the device generator (training runs);
                 noise_injection([...("gumbel"|"rand", tensor)...]) consumed in call order -> parity runs
                 (thread-local).
@@ -105,7 +108,7 @@ def tuning_env(name, default):
     return v
 
 
-_DEFAULTS = dict(compute_dtype=torch.float32, f32_split=False, cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
+_DEFAULTS = dict(compute_dtype=torch.float32, f32_split=False, c_exec=tuning_env("SEGCLIP_C_EXEC", "1") != "0", cross_mode="t18", overlap_wgrad=False, overlap_towers=True,
                  trust_weight_shadows=False, attn_fp8=False, fuse_res_stack=True, bf16_resgrad=True, bf16_resid=False, fused_head=True, reduce_side=False,
                  aux_u8=tuning_env("SEGCLIP_AUX_U8", "1") != "0",
                  text_after_blocks=3, text_trim=False, text_trim_hint=None, pad_rows=tuning_env("SEGCLIP_PAD_ROWS", "1") != "0", fold_param_grads=tuning_env("SEGCLIP_FOLD_GRADS", "1") != "0",

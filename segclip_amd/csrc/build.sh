@@ -47,7 +47,7 @@ for part in 0 1 2 3 4; do
     pids+=($!)
   fi
 done
-for f in gemm_f32.hip layernorm.hip attention.hip misc.hip group_linear.hip head.hip center.hip optim.hip capi.cpp; do
+for f in gemm_f32.hip layernorm.hip attention.hip misc.hip group_linear.hip head.hip center.hip optim.hip capi.cpp exec.cpp; do
   [ -f "$f" ] || continue
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then

@@ -944,6 +944,55 @@ class ActFn(Function):
         return dx, None
 
 
+def _resblock_fwd_exec(x2, P, B, T, n_head, causal, act, eps, klen):
+    """config.c_exec: the block's seven forward launches enqueued by ONE C-ABI call (segclip_resblock_fwd, csrc/exec.cpp) into
+    buffers allocated here - the same kernels with the same descriptors as the launch-by-launch path below, so results are
+    bit-identical; ~60 us of host time per block instead of ~300.  Returns None when the library has no kernel for a shape in
+    the fused form (the caller then takes the launch-by-launch path)."""
+    ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = P
+    M, D = x2.shape
+    F4 = wfc.shape[0]
+    bf = torch.bfloat16
+    dev = x2.device
+    wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, bf) for w in (wqkv, wo, wfc, wpr))
+    ak = _aux_kind(bf, act, M, F4)
+    y1 = torch.empty((M, D), dtype=bf, device=dev)
+    y2 = torch.empty((M, D), dtype=bf, device=dev)
+    o = torch.empty((M, D), dtype=bf, device=dev)
+    qkv = torch.empty((M, 3 * D), dtype=bf, device=dev)
+    st4 = torch.empty((4, M), dtype=torch.float32, device=dev)     # mean1 | rstd1 | mean2 | rstd2
+    x1 = torch.empty((M, D), dtype=x2.dtype, device=dev)
+    xo = torch.empty((M, D), dtype=x2.dtype, device=dev)
+    h = _empty_pitched((M, F4), bf, x2)
+    u = (_empty_pitched((M, F4), torch.uint8 if ak == 2 else bf, x2)) if act != ACT_NONE else None
+    stats = torch.empty((B * n_head * T,), dtype=torch.float32, device=dev)
+    d = L.ResBlockFwdDesc()
+    d.x = x2.data_ptr()
+    d.ln1w, d.ln1b, d.wqkv, d.bqkv = ln1w.data_ptr(), ln1b.data_ptr(), wqkv_c.data_ptr(), bqkv.data_ptr()
+    d.wo, d.bo, d.ln2w, d.ln2b = wo_c.data_ptr(), bo.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr()
+    d.wfc, d.bfc, d.wpr, d.bpr = wfc_c.data_ptr(), bfc.data_ptr(), wpr_c.data_ptr(), bpr.data_ptr()
+    d.y1, d.mean1, d.rstd1 = y1.data_ptr(), st4.data_ptr(), st4.data_ptr() + 4 * M
+    d.qkv, d.o, d.stats, d.x1 = qkv.data_ptr(), o.data_ptr(), stats.data_ptr(), x1.data_ptr()
+    d.y2, d.mean2, d.rstd2 = y2.data_ptr(), st4.data_ptr() + 8 * M, st4.data_ptr() + 12 * M
+    d.h, d.ld_h = h.data_ptr(), h.stride(0)
+    if u is not None:
+        d.u, d.ld_u = u.data_ptr(), u.stride(0)
+    d.xo = xo.data_ptr()
+    if klen is not None:
+        if klen.dtype != torch.int32 or klen.numel() != B or not klen.is_contiguous():
+            raise TypeError("attention: klen must be a contiguous int32 tensor of B entries")
+        d.klen = klen.data_ptr()
+    d.M, d.B, d.T, d.D, d.F, d.H = M, B, T, D, F4, n_head
+    d.eps, d.attn_scale = float(eps), 1.0 / math.sqrt(D // n_head)
+    d.causal, d.act, d.aux_kind, d.x_dtype = int(causal), int(act), int(ak), L.dt(x2)
+    try:
+        L.check(L.load().segclip_resblock_fwd(C.byref(d), L.stream()), "resblock_fwd")
+    except L.Unsupported:
+        return None
+    saved = (x2, ln1w, st4[0], st4[1], y1, wqkv_c, qkv, o, stats, wo_c, x1, ln2w, st4[2], st4[3], y2, wfc_c, u, h, wpr_c)
+    return xo, saved
+
+
 def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
     """One pre-LN residual block on the (B*T, D) residual stream x2 - fp32, or bf16 inside a ResStackFn running with
     config.bf16_resid - : returns (x_out (B*T, D) in the stream's dtype, tensors saved for backward)."""
@@ -954,6 +1003,12 @@ def _resblock_fwd(x2, P, B, T, n_head, causal, act, eps, act_dtype, klen):
         sl = _slot_of(w)
         if sl is not None:
             sl.note_forward_use()
+    from . import config as _cfg
+    if (act_dtype == torch.bfloat16 and _cfg.c_exec and not _OpCount.enabled and not _GemmProfile.enabled and not _cfg.attn_fp8
+            and x2.is_contiguous() and D % 8 == 0):
+        r = _resblock_fwd_exec(x2, P, B, T, n_head, causal, act, eps, klen)
+        if r is not None:
+            return r
     y1, mean1, rstd1 = p_ln_fwd(x2, ln1w, ln1b, eps, act_dtype)
     wqkv_c, wo_c, wfc_c, wpr_c = (wcast(w, act_dtype) for w in (wqkv, wo, wfc, wpr))
     qkv, _ = p_linear(y1, wqkv_c, bqkv)
