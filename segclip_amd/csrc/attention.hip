@@ -319,6 +319,7 @@ struct BwdArgs {
   float* colsum_part;  // nullable: [B][3][H*hd] token sums of dQ | dK | dV (the in_proj bias gradient, per sample)
   int abl;             // experiments (SEGCLIP_ATTN_ABL): 0 = the kernel; see attention_sp.inc
   int nitems;          // single-pass kernel: B * H items, walked by a persistent grid
+  float* ws;           // attention_dqw.inc, sequences of more than 224 tokens: fp32 dQ accumulators across key chunks
 };
 
 constexpr int TMAX = 256;
@@ -706,19 +707,26 @@ int launch_fwd_pf(const FwdArgs& a, int nitems, hipStream_t stream) {
 }
 
 // streaming backward with a dQ wave (attention_dqw.inc): one workgroup of NT + 1 waves per CU walks its share of the items
-template <int NT>
+template <int NT, bool MULTI>
 int launch_bwd_dqw(const BwdArgs& a, int ncu, int dev, hipStream_t stream) {
   static bool attr_set[64] = {};
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dqw_bf16_kernel<NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dqw_bf16_kernel<NT, MULTI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SEGCLIP_REQUIRE(e == hipSuccess, "attn_bwd bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set[dev] = true;
   }
   const int grid = a.nitems < ncu ? a.nitems : ncu;
-  hipLaunchKernelGGL((attn_bwd_dqw_bf16_kernel<NT>), dim3((unsigned)grid), dim3((NT + 1) * 64), bwd_dqw_lds_bytes<NT>(), stream, a);
+  hipLaunchKernelGGL((attn_bwd_dqw_bf16_kernel<NT, MULTI>), dim3((unsigned)grid), dim3((NT + 1) * 64), bwd_dqw_lds_bytes<NT>(), stream, a);
   SEGCLIP_CHECK_LAUNCH("attn_bwd_dqw_bf16");
   return 0;
+}
+
+// workgroups of the key-chunked dqw launch: the CUs of the current device
+int dqw_multi_max_grid() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  return n;
 }
 
 }  // namespace
@@ -730,7 +738,10 @@ extern "C" size_t segclip_attn_stats_bytes(const segclip_attn_desc* d) {
 extern "C" size_t segclip_attn_bwd_ws_bytes(const segclip_attn_desc* d) {
   if (d->dtype == SEGCLIP_BF16) {
     if (d->Tq <= TMAX && d->Tk <= TMAX) return 0;
-    return (size_t)d->B * d->H * (d->Tq + d->Tk) * sizeof(float);  // streaming kernels: cs[key] and D[q]
+    const size_t stream_ws = (size_t)d->B * d->H * (d->Tq + d->Tk) * sizeof(float);  // streaming kernels: cs[key] and D[q]
+    // attention_dqw.inc, key-chunked: 8 KB of fp32 dQ accumulators per query tile and workgroup (one workgroup per CU)
+    const size_t dqw_ws = (size_t)dqw_multi_max_grid() * (size_t)(d->Tq / 32 + 1) * 8192;
+    return stream_ws > dqw_ws ? stream_ws : dqw_ws;
   }
   return (size_t)d->B * d->H * d->Tq * d->Tk * sizeof(float);
 }
@@ -848,6 +859,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
     static const int abl_env = segclip_ablation_env("SEGCLIP_ATTN_ABL");
     a.abl = abl_env;
     a.nitems = (int)(d->B * d->H);
+    a.ws = (float*)d->ws;
     if (smallq::covers(d)) {
       hipLaunchKernelGGL(smallq::attn_smallq_bwd_kernel, dim3((unsigned)cdiv(a.nitems, smallq::WPB_BWD)), dim3(smallq::WPB_BWD * 64),
                          smallq::lds_bytes((int)d->Tk, true), stream, a, a.nitems);
@@ -858,6 +870,15 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
       SEGCLIP_REQUIRE(d->klen == nullptr, "attn_bwd bf16: klen needs sequences of at most %d tokens", TMAX);
       // long sequences: two streaming launches (dK,dV | dQ), 8 owned tiles per workgroup
       SEGCLIP_REQUIRE(d->ws != nullptr, "attn_bwd bf16: workspace required for sequences longer than %d", TMAX);
+      // unmasked self-attention, head_dim 64: the dQ-wave kernel over chunks of 224 keys (attention_dqw.inc, MULTI).
+      // SEGCLIP_ATTN_BWD_DQW_LONG=0 (tuning) keeps the two streaming launches
+      static const int use_dqw_long = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_DQW_LONG"); return e ? atoi(e) : 1; }();
+      // (its token sums ride on a padded key in the last chunk and on two padded rows of the last query tile)
+      if (use_dqw_long && d->Tq == d->Tk && !d->causal && d->hd == 64 && d->Tq % 32 <= 30 && d->Tq % 224 != 0) {
+        int dev = 0;
+        SEGCLIP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "attn_bwd: cannot query the current device");
+        return launch_bwd_dqw<7, true>(a, dqw_multi_max_grid(), dev, stream);
+      }
       const size_t lds = bwd_stream_lds_bytes();
       static bool attr_set = false;
       if (!attr_set) {
@@ -918,7 +939,7 @@ extern "C" int segclip_attn_bwd(const segclip_attn_desc* d, void* stream_) {
       // (attention_dqw.inc, round 6); SEGCLIP_ATTN_BWD_DQW=0 keeps the kernels below
       static const int use_dqw = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_DQW"); return e ? atoi(e) : 1; }();
       if (use_dqw && !masked && d->hd == 64 && tiles == 7 && d->Tq % 32 >= 1 && d->Tq % 32 <= 30)
-        return launch_bwd_dqw<7>(a, ncu, dev, stream);
+        return launch_bwd_dqw<7, false>(a, ncu, dev, stream);
       // vision tower (no mask, 5-7 tiles): the variant whose memory traffic is issued by a loader wave (attention_spl.inc);
       // SEGCLIP_ATTN_BWD_SPL=0 keeps attention_sp.inc
       static const int use_spl = [] { const char* e = segclip_tuning_env("SEGCLIP_ATTN_BWD_SPL"); return e ? atoi(e) : 1; }();

@@ -364,8 +364,15 @@ def _attn_ref(q, k, v, H, causal):
                                              # tokens have no two padded rows for the token sums and stay on the loader-wave kernel
                                              (3, 193, 2, 64, False), (2, 222, 3, 64, False), (1, 197, 1, 64, False), (30, 200, 12, 64, False),
                                              (3, 223, 2, 64, False), (2, 224, 2, 64, False),
-                                             # > 256 tokens: the streaming backward (ViT-L/14 at 336^2: 576 patches)
-                                             (2, 576, 16, 64, False), (1, 300, 2, 64, True), (1, 784, 3, 64, False)])
+                                             # > 256 tokens (ViT-L/14 at 336^2: 576 patches): the dQ-wave kernel over chunks of 224 keys
+                                             # (attention_dqw.inc MULTI; 576 = 18 full query tiles + one padded, last chunk of 128 keys),
+                                             # causal: the two streaming launches
+                                             (2, 576, 16, 64, False), (1, 300, 2, 64, True), (1, 784, 3, 64, False),
+                                             # ... a last chunk of ONE key, two chunks, more items than workgroups (units of several items
+                                             # back to back), and the lengths it does not take (no padded key: 448 = 2 x 224; no two
+                                             # padded query rows: 319 = 9 x 32 + 31), which stay on the streaming launches
+                                             (2, 577, 3, 64, False), (1, 257, 1, 64, False), (3, 449, 2, 64, False), (300, 288, 1, 64, False),
+                                             (1, 448, 2, 64, False), (1, 319, 2, 64, False)])
 def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
     """Packed-QKV self attention exactly as ResBlockFn drives it (forward + backward)."""
     D = H * hd

@@ -5,7 +5,12 @@ import math, os, subprocess, sys, tempfile
 os.environ.setdefault("SEGCLIP_TUNING", "1")   # the library honours its kernel-selection switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # B, T, H, hd
-CASES = [(256, 196, 12, 64), (5, 197, 8, 64), (3, 222, 2, 64), (300, 196, 12, 64), (2, 193, 3, 64), (700, 200, 5, 64), (2, 196, 3, 64), (1, 196, 1, 64), (23, 211, 12, 64)]
+# `python tools/check_attn_dqw.py long`: the key-chunked variant for sequences of more than 256 tokens (SEGCLIP_ATTN_BWD_DQW_LONG)
+# against the two streaming launches it replaces
+LONG = os.environ.get("SEGCLIP_CHECK_LONG") == "1" or (len(sys.argv) > 1 and sys.argv[1] == "long")
+SWITCH = "SEGCLIP_ATTN_BWD_DQW_LONG" if LONG else "SEGCLIP_ATTN_BWD_DQW"
+CASES_LONG = [(128, 576, 16, 64), (2, 576, 3, 64), (3, 288, 2, 64), (2, 320, 1, 64), (128, 577, 16, 64), (2, 577, 3, 64), (1, 257, 1, 64), (3, 449, 2, 64), (2, 478, 5, 64), (1, 1021, 2, 64), (40, 290, 7, 64), (600, 321, 1, 64)]
+CASES = CASES_LONG if LONG else [(256, 196, 12, 64), (5, 197, 8, 64), (3, 222, 2, 64), (300, 196, 12, 64), (2, 193, 3, 64), (700, 200, 5, 64), (2, 196, 3, 64), (1, 196, 1, 64), (23, 211, 12, 64)]
 
 
 def run(path):
@@ -29,7 +34,7 @@ def run(path):
         out[f"d{i}"] = dqkv.float().cpu(); out[f"c{i}"] = cs.cpu()
         if i == 0:
             t = timeit(lambda: ops.p_attn_bwd(desc(), stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=cs))
-            print(f"DQW={os.environ.get('SEGCLIP_ATTN_BWD_DQW', '0')}: B{B} T{T} H{H} bwd {t * 1e6:.1f} us", flush=True)
+            print(f"{SWITCH}={os.environ.get(SWITCH, '0')}: B{B} T{T} H{H} bwd {t * 1e6:.1f} us", flush=True)
         if B * T <= 4096:   # fp32 reference
             q, k, v = (qkv[:, j * D:(j + 1) * D].float().view(B, T, H, hd).transpose(1, 2).requires_grad_() for j in range(3))
             p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)
@@ -40,14 +45,14 @@ def run(path):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 1 and sys.argv[1] != "long":
         run(sys.argv[1]); sys.exit(0)
     import torch
     with tempfile.TemporaryDirectory() as td:
         res = []
         for sq in ("0", "1"):
             p = os.path.join(td, f"dqw{sq}.pt")
-            subprocess.run([sys.executable, __file__, p], check=True, env=dict(os.environ, SEGCLIP_TUNING="1", SEGCLIP_ATTN_BWD_DQW=sq))
+            subprocess.run([sys.executable, __file__, p], check=True, env=dict(os.environ, SEGCLIP_TUNING="1", SEGCLIP_CHECK_LONG="1" if LONG else "0", **{SWITCH: sq}))
             res.append(torch.load(p))
         bad = 0
         for k in sorted(res[0]):
