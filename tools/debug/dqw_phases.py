@@ -24,8 +24,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = dbg.view(torch.float32)[:256 * 8 * 8].view(256, 8, 8).double()
 items, steps = 12, 12 * 7
-kn = ["barrier", "park dK + memory issue (pos 0)", "K/V frags + S/dP next tile + D share (+ mem pos 1)", "softmax + park dS (+ mem pos 2)", "dV/dK products (issue) (+ mem pos 3)", "end of step (lgkmcnt, vmcnt)", "end of item (X barrier, park dV)"]
-k = t[:, :7, :7]
+kn = ["barrier", "park dK + memory issue (pos 0)", "K/V frags + S/dP next tile + D share (+ mem pos 1)", "softmax + park dS (+ mem pos 2)", "dV/dK products (issue) (+ mem pos 3)", "end of step (lgkmcnt, vmcnt)", "end of item (next K / V fragments, park dV)", "barrier K + park dK (step 0 of an item)"]
+k = t[:, :7, :8]
 tot = k.sum(-1).mean()
 print(f"key-owner waves: {tot:.0f} cycles = {tot / items:.0f} per item = {tot / steps:.0f} per step")
 for i, n in enumerate(kn):
