@@ -37,3 +37,7 @@ print(f"total GEMM time {tot*1e3:.2f} ms, {len(rec)} launches (launches inside s
 print("M N K | A_kcontig B_kcontig batch Adt Cdt res act dact caller | calls  total_ms  avg_us  TF/s")
 for s, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(s[:11], a[0], f"{a[1]*1e3:8.3f} {a[1]/a[0]*1e6:8.1f} {a[2]/max(a[1],1e-9)/1e12:7.1f}", s[11])
+print("fp32-operand GEMMs:")
+for s, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    if s[6] == 'at32':
+        print(s[:11], a[0], f"{a[1]*1e3:8.3f} {a[1]/a[0]*1e6:8.1f} {a[2]/max(a[1],1e-9)/1e12:7.1f}", s[11])
