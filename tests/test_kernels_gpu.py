@@ -401,6 +401,38 @@ def test_self_attention_block_packed_qkv(dtype, B, T, H, hd, causal):
         close(part[:, 2 * D:], do.float().view(B, T, D).sum(1), 1e-3, 1e-3, "dv colsum == colsum(dO)")
 
 
+@pytest.mark.parametrize("B,T,H", [(300, 196, 12), (7, 222, 3), (128, 576, 16), (40, 290, 7)])
+def test_attention_dqw_backward_is_deterministic_under_memory_contention(B, T, H):
+    """Race hunt for attention_dqw.inc (one barrier per step, software-counted vmcnt over mixed LDS-DMA loads and stores, fp32 workspace
+    tiles across key chunks): the same backward repeated on the same inputs, every other run beside a copy loop on a second stream
+    (the memory latencies vary), must give bit-identical dQ | dK | dV and token sums (tools/debug/dqw_stress.py is the long form)."""
+    hd, D = 64, H * 64
+    qkv = rnd(B * T, 3 * D, dtype=BF, seed=91)
+    do = rnd(B * T, D, dtype=BF, seed=92)
+    o = torch.empty(B * T, D, dtype=BF, device=DEV)
+    s3 = (T * 3 * D, 3 * D)
+    desc = lambda: ops._attn_desc(qkv, qkv, qkv, o, B, H, T, T, hd, s3, s3, s3, (T * D, D), 1 / math.sqrt(hd), False, 0, D, 2 * D)
+    stats = ops.p_attn_fwd(desc(), qkv)
+    side = torch.cuda.Stream()
+    junk = torch.empty(128 << 20, dtype=torch.uint8, device=DEV)
+    ref = None
+    for i in range(12):
+        dqkv = torch.full_like(qkv, float("nan"))
+        cs = torch.full((B, 3 * D), float("nan"), dtype=torch.float32, device=DEV)
+        if i % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    junk[: 64 << 20].copy_(junk[64 << 20:])
+        ops.p_attn_bwd(desc(), stats, do, dqkv, dqkv, dqkv, s3, s3, s3, (T * D, D), 0, D, 2 * D, colsum_part=cs)
+        torch.cuda.synchronize()
+        if ref is None:
+            assert not dqkv.isnan().any() and not cs.isnan().any()
+            ref = (dqkv.clone(), cs.clone())
+        else:
+            assert torch.equal(dqkv.view(torch.int16), ref[0].view(torch.int16)), f"run {i}: dQ|dK|dV differ from run 0"
+            assert torch.equal(cs.view(torch.int32), ref[1].view(torch.int32)), f"run {i}: token sums differ from run 0"
+
+
 @pytest.mark.parametrize("B,T,H,hd,causal", [(2, 576, 16, 64, False), (2, 196, 12, 64, False), (3, 77, 8, 64, True),
                                              (1, 300, 2, 64, False), (2, 40, 2, 32, False)])
 def test_self_attention_fp8_forward(B, T, H, hd, causal):

@@ -7,11 +7,13 @@ import segclip_amd
 from segclip_amd import ops, synth
 segclip_amd.set_compute_dtype(torch.bfloat16)
 segclip_amd.config.overlap_towers = False
-spec = synth.SPECS["vitb16"]
+# usage: full_gemms.py [batch [spec [full_loss 0|1]]]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-model, _ = synth.build_model(spec, dict(use_seglabel=True, use_vision_mae_recon=True), device="cuda")
+spec = synth.SPECS[sys.argv[2] if len(sys.argv) > 2 else "vitb16"]
+FULL = (sys.argv[3] if len(sys.argv) > 3 else "1") == "1"
+model, _ = synth.build_model(spec, dict(use_seglabel=True, use_vision_mae_recon=True) if FULL else {}, device="cuda")
 model.clip.visual.conv1.weight.requires_grad_(False); model.clip.visual.positional_embedding.requires_grad_(False)
-batch = synth.synthetic_batch(spec, B, seed=1, device="cuda", with_seg=True)
+batch = synth.synthetic_batch(spec, B, seed=1, device="cuda", with_seg=FULL)
 def step():
     model.zero_grad(set_to_none=True)
     loss = model(batch["input_ids"], batch["segment_ids"], batch["input_mask"], batch["image"], image_seg=batch.get("image_seg"))
