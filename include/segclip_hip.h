@@ -48,7 +48,7 @@ const char* segclip_last_error_string(void);
  *   aux_kind 1: aux holds act'(pre-activation) instead of the pre-activation - the forward epilogue stores the
  *               derivative (its exponential is already computed there) and mul_dact multiplies by aux as it is
  *   aux_kind 2: as 1, but aux is ONE BYTE per element, q = rint((act'(v) + 0.125) * 204) (QuickGELU': [-0.10, 1.10],
- *               absolute error <= 0.0025); ldaux in bytes; bf16 operands and output, full 256 x 256 tiles (M, N
+ *               absolute error <= 0.0025; erf-GELU': [-0.129, 1.129], the two extremes saturate: <= 0.0065); ldaux in bytes; bf16 operands and output, full 256 x 256 tiles (M, N
  *               multiples of 256), 16-byte aligned operands, ldaux % 8 == 0, no split-K - otherwise
  *               SEGCLIP_ERR_UNSUPPORTED (callers fall back to aux_kind 1)
  * Replaces nn.Linear / MHA in-proj / out-proj / the einsum + Conv1d contractions:

@@ -40,7 +40,8 @@ bf16_resid    : bf16 mode, inside ResStackFn: the residual STREAM itself is bf16
                 LayerNorm pass move 2 bytes less per element.  Implies the bf16 gradient chain
 aux_u8        : bf16 mode: the towers keep QuickGELU'(u) for the backward as ONE BYTE per element where the MLP GEMMs run
                 on full 256 x 256 tiles (q = rint((act' + 0.125) * 204), absolute error <= 0.0025 - about bf16's relative
-                error at the typical magnitude, unbounded RELATIVE error near act' = 0); False keeps it as bf16
+                error at the typical magnitude, unbounded RELATIVE error near act' = 0); False keeps it as bf16.  Round 6: the
+                MAE decoders' erf-GELU likewise where the 256 x 256-tile GEMM takes the shape (else: the pre-activation as bf16)
 fused_head    : training forward: max-token pooling + ln_post + projection on the pooled row only, and the contrastive head
                 (L2-normalise, all-gather, logits, both cross entropies) as ONE autograd node (ops.ClipLossFn) - ~15 instead
                 of ~90 launches between the last forward GEMM and the first backward GEMM; False: the op-by-op path

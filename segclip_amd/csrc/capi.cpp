@@ -37,8 +37,9 @@ extern "C" int segclip_gemm(const segclip_gemm_desc* d, void* stream) {
   if (d->M == 0 || d->N == 0) return 0;
   SEGCLIP_REQUIRE(d->A && d->B && d->C, "gemm: null operand");
   SEGCLIP_REQUIRE(!d->mul_dact || d->aux, "gemm: mul_dact needs aux");
-  SEGCLIP_REQUIRE(d->aux_kind == 0 || ((d->aux_kind == 1 || d->aux_kind == 2) && d->act == SEGCLIP_ACT_QUICK_GELU),
-                  "gemm: aux_kind 1 / 2 (aux = act'(pre-activation)) is implemented for QuickGELU only");
+  SEGCLIP_REQUIRE(d->aux_kind == 0 || ((d->aux_kind == 1 || d->aux_kind == 2) && d->act == SEGCLIP_ACT_QUICK_GELU) ||
+                      (d->aux_kind == 2 && d->act == SEGCLIP_ACT_GELU_ERF),
+                  "gemm: aux_kind 1 (aux = act'(pre-activation) in the output type) is implemented for QuickGELU only, aux_kind 2 for QuickGELU and erf-GELU");
   SEGCLIP_REQUIRE(d->aux_kind != 2 || (d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16 && d->c_dtype == SEGCLIP_BF16),
                   "gemm: aux_kind 2 (one byte per element) needs bf16 operands and output");
   if (d->res_row_mod > 0 && !(d->a_dtype == SEGCLIP_BF16 && d->b_dtype == SEGCLIP_BF16)) {

@@ -356,6 +356,8 @@ bool segclip_gemm_bf16_dma_try(const segclip_gemm_desc* d, const void* args_, in
                 d->bsC2 % ce == 0 && (!d->residual || (d->bsR1 % re == 0 && d->bsR2 % re == 0));
     if (d->residual && d->r_dtype != d->c_dtype) g.vec_epi = 0;   // the LDS epilogue holds side operands in the output type
     if (g.colsum_part && !g.vec_epi) return false;
+    // the one-byte derivative of the erf-GELU is produced by gemm_bf16_pq.hip only (this epilogue: QuickGELU); decoding is generic
+    if (d->aux_kind == 2 && d->aux && !d->mul_dact && d->act != SEGCLIP_ACT_QUICK_GELU) return false;
     // aux_kind 2 (one byte per saved derivative) exists in the staged epilogue of FULL tiles only (8-byte aligned rows)
     if (d->aux_kind == 2 && d->aux &&
         !(g.vec_epi && d->M % 256 == 0 && d->N % 256 == 0 && d->ldaux % 8 == 0 && d->c_dtype == SEGCLIP_BF16 && splits == 1))

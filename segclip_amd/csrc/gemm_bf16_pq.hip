@@ -52,7 +52,9 @@ constexpr int BIAS_OFF = EXTRA;               // bias: wave * 256 B (modes with 
 constexpr int HSLOT = 3 * UNIT;
 constexpr int BIAS_OFF_H = 3 * HSLOT;         // 144 KiB
 
-enum { PQ_PLAIN = 0, PQ_RES = 1, PQ_ACT8 = 2, PQ_DACT8 = 3, PQ_SLAB = 4, PQ_RES32 = 5 };
+enum { PQ_PLAIN = 0, PQ_RES = 1, PQ_ACT8 = 2, PQ_DACT8 = 3, PQ_SLAB = 4, PQ_RES32 = 5, PQ_ACT8E = 6 };
+// PQ_ACT8E: PQ_ACT8 with the erf-GELU of the MAE decoders (modules/module_mae.py:110-134: timm Block, nn.GELU) instead of QuickGELU
+template <int MODE> constexpr bool pq_is_act8() { return MODE == PQ_ACT8 || MODE == PQ_ACT8E; }
 
 struct PQArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C; const float* bias;
@@ -290,6 +292,35 @@ __device__ __forceinline__ void pq_block(const PQArgs& g, lds_char* sm, const f3
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) w[k] = v[gq * 4 + k] + bias[gq][k];
+    }
+    if constexpr (MODE == PQ_ACT8E) {
+      // erf-GELU and its derivative on pairs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: one rcp, one exp2 - the
+      // exponential the derivative's Gaussian needs anyway - and a degree-5 polynomial), Phi(x) = 1 - q / 2 (x >= 0) | q / 2
+      uint32_t q = 0;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const v2f x = v2f{w[2 * k2], w[2 * k2 + 1]};
+        const v2f ax = v2f{__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+        const v2f td = ax * v2f{0.2316418882f, 0.2316418882f} + v2f{1.0f, 1.0f};          // 1 + 0.3275911 |x| / sqrt 2
+        const v2f t = v2f{__builtin_amdgcn_rcpf(td[0]), __builtin_amdgcn_rcpf(td[1])};
+        const v2f ee = (x * v2f{-0.7213475204f, -0.7213475204f}) * x;                      // -x^2 / 2 * log2 e
+        const v2f E = v2f{__builtin_amdgcn_exp2f(ee[0]), __builtin_amdgcn_exp2f(ee[1])};   // exp(-x^2 / 2)
+        v2f pl = t * v2f{1.061405429f, 1.061405429f} + v2f{-1.453152027f, -1.453152027f};
+        pl = pl * t + v2f{1.421413741f, 1.421413741f};
+        pl = pl * t + v2f{-0.284496736f, -0.284496736f};
+        pl = pl * t + v2f{0.254829592f, 0.254829592f};
+        const v2f hq = ((pl * t) * E) * v2f{0.5f, 0.5f};                                   // (1 - erf(|x| / sqrt 2)) / 2
+        const v2f up = v2f{1.0f, 1.0f} - hq;
+        const v2f phi = v2f{x[0] >= 0.f ? up[0] : hq[0], x[1] >= 0.f ? up[1] : hq[1]};
+        const v2f y = x * phi;
+        const v2f sd = (x * E) * v2f{0.3989422804f, 0.3989422804f} + phi;                  // act'(u) = Phi + x phi(x)
+        const v2f qf = sd * v2f{AUX8_SCALE, AUX8_SCALE} + v2f{AUX8_OFF * AUX8_SCALE, AUX8_OFF * AUX8_SCALE};
+        w[2 * k2] = y[0]; w[2 * k2 + 1] = y[1];
+        q = __builtin_amdgcn_cvt_pk_u8_f32(qf[0], 2 * k2, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(qf[1], 2 * k2 + 1, q);
+      }
+      *reinterpret_cast<lds_u32*>(sm + AO_OFF + J * 16384 + row128 + (c8 << 4) +
+                                  ((((gq & 1) * 2 + lk) ^ ((li >> 3) & 3)) << 2)) = q;
     }
     if constexpr (MODE == PQ_ACT8) {
       // QuickGELU and its derivative on PAIRS (v_pk_mul / v_pk_add / v_pk_fma_f32: the same IEEE operations as the scalar
@@ -569,7 +600,7 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_void*)smem);
 
   // ---- side operands that travel during the K loop (oldest entries of the VM queue: the first counted wait covers them)
-  constexpr bool HAS_BIAS = MODE == PQ_PLAIN || MODE == PQ_ACT8;   // bias added in the accumulator layout (PQ_RES: in the row pass)
+  constexpr bool HAS_BIAS = MODE == PQ_PLAIN || pq_is_act8<MODE>();   // bias added in the accumulator layout (PQ_RES: in the row pass)
   const bool has_bias = HAS_BIAS && g.bias != nullptr;
   if (has_bias)   // this wave's 2 x 32 columns: lane l -> column (l>>5)*128 + wc*32 + (l&31)
     dma4(g.bias + n0 + wc * 32, (uint32_t)(((lane >> 5) * 128 + (lane & 31)) * 4), lds0 + (half ? BIAS_OFF_H : BIAS_OFF) + wave * 256);
@@ -898,7 +929,7 @@ __device__ __forceinline__ void pq_main(const PQArgs& g, const int unit_given) {
     } else {                                                                   \
       pq_rows_half<MODE, I>(g, sm3, lane, wave, m0, n0);                       \
     }                                                                          \
-    if constexpr (MODE == PQ_ACT8) pq_rows_aux<I>(g, sm3, lane, wave, m0, n0); \
+    if constexpr (pq_is_act8<MODE>()) pq_rows_aux<I>(g, sm3, lane, wave, m0, n0); \
   } while (0)
   PQ_HALF(0, (MODE == PQ_DACT8 && half ? SI1_OFF : SI0_OFF), res0);
   if (HALF_OK && half) return;   // half-tile workgroup: 128 rows only
@@ -941,6 +972,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_bf16_pq_group_kernel(PQArgs g, 
 void segclip_pq_launch_f(int mode, dim3 grid, hipStream_t stream, const void* args) {   // forward: plain / QuickGELU + saved derivative / + residual
   const PQArgs g = *reinterpret_cast<const PQArgs*>(args);
   if (mode == PQ_ACT8) PQ_LAUNCH(false, false, PQ_ACT8);
+  else if (mode == PQ_ACT8E) PQ_LAUNCH(false, false, PQ_ACT8E);
   else if (mode == PQ_RES) PQ_LAUNCH(false, false, PQ_RES);
   else if (mode == PQ_RES32) PQ_LAUNCH(false, false, PQ_RES32);
   else PQ_LAUNCH(false, false, PQ_PLAIN);
@@ -1099,11 +1131,13 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
     mode = PQ_RES;
   } else
   if (d->mul_dact) {            // x act'(u), saved as one byte; optional fused column sums
-    if (!(d->aux && d->aux_kind == 2 && d->act == SEGCLIP_ACT_QUICK_GELU && !d->bias && b_ks && d->ldaux % 16 == 0)) return false;
+    const bool gelu = d->act == SEGCLIP_ACT_QUICK_GELU || d->act == SEGCLIP_ACT_GELU_ERF;   // (the byte is decoded the same way)
+    if (!(d->aux && d->aux_kind == 2 && gelu && !d->bias && b_ks && d->ldaux % 16 == 0)) return false;
     mode = PQ_DACT8;
-  } else if (d->act != SEGCLIP_ACT_NONE) {   // QuickGELU + saved derivative as one byte
-    if (!(d->aux && d->aux_kind == 2 && d->act == SEGCLIP_ACT_QUICK_GELU && !b_ks && d->ldaux % 16 == 0)) return false;
-    mode = PQ_ACT8;
+  } else if (d->act != SEGCLIP_ACT_NONE) {   // QuickGELU / erf-GELU + saved derivative as one byte
+    const bool gelu = d->act == SEGCLIP_ACT_QUICK_GELU || d->act == SEGCLIP_ACT_GELU_ERF;
+    if (!(d->aux && d->aux_kind == 2 && gelu && !b_ks && d->ldaux % 16 == 0)) return false;
+    mode = d->act == SEGCLIP_ACT_QUICK_GELU ? PQ_ACT8 : PQ_ACT8E;
   } else if (d->aux) {
     return false;
   }
@@ -1119,7 +1153,7 @@ bool segclip_gemm_bf16_pq_try(const segclip_gemm_desc* d, const void* args_, int
   g.A = reinterpret_cast<const bf16_t*>(d->A); g.B = reinterpret_cast<const bf16_t*>(d->B);
   g.C = reinterpret_cast<bf16_t*>(d->C); g.bias = d->bias;
   g.side = mode == PQ_DACT8 ? d->aux : (mode == PQ_RES ? d->residual : nullptr);
-  g.aux = mode == PQ_ACT8 ? reinterpret_cast<uint8_t*>(d->aux) : nullptr;
+  g.aux = (mode == PQ_ACT8 || mode == PQ_ACT8E) ? reinterpret_cast<uint8_t*>(d->aux) : nullptr;
   g.colsum_part = a.colsum_part;
   g.lda = lda; g.ldb = ldb; g.ldc = d->ldc; g.lds = mode == PQ_RES ? d->ldr : d->ldaux; g.ldaux = d->ldaux;
   g.N = (int)d->N; g.K = (int)d->K; g.nbx = (int)(d->N / BT); g.ntiles = (int)((d->M / BT) * (d->N / BT));

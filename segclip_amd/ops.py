@@ -378,10 +378,12 @@ def p_linear(x, w, bias=None, act=ACT_NONE, residual=None, want_aux=False, out_d
         if aux_kind != 2 or aux is None:
             raise
         # the one-byte derivative needs full 256 x 256 tiles and 16-byte aligned operands (include/segclip_hip.h): keep it
-        # as bf16 instead (aux_kind 1); the backward reads the form off the tensor's dtype
+        # as bf16 instead (QuickGELU: aux_kind 1; erf-GELU: the pre-activation itself, aux_kind 0); the backward reads the
+        # form off the tensor's dtype
         aux = alloc((M, N), out_dtype, x)
         p_gemm(x, w, y, M, N, K, (_ld(x), 1), sb, _ld(y), bias=bias, residual=residual,
-               ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux), act=act, aux_kind=1)
+               ldr=_ld(residual) if residual is not None else 0, aux=aux, ldaux=_ld(aux), act=act,
+               aux_kind=1 if act == ACT_QUICK_GELU else 0)
     return y, aux
 
 
@@ -1041,6 +1043,11 @@ def _aux_kind(act_dtype, act, M=0, N=0):
     if act_dtype == torch.bfloat16 and act == ACT_QUICK_GELU:
         from . import config as _cfg
         return 2 if (_cfg.aux_u8 and M > 0 and M % 128 == 0 and N % 256 == 0) else 1
+    if act_dtype == torch.bfloat16 and act == ACT_GELU_ERF:
+        # round 6: the MAE decoders' erf-GELU keeps the one-byte derivative as well where the 256 x 256-tile GEMM takes the shape
+        # (c_fc forward 172 -> 9x us, the c_proj data gradient no longer re-evaluates erf per element: 247 -> 1xx us at M = 50432)
+        from . import config as _cfg
+        return 2 if (_cfg.aux_u8 and M > 0 and M % 128 == 0 and N % 256 == 0) else 0
     return 0
 
 

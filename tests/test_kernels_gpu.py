@@ -145,6 +145,38 @@ def test_gemm_saved_derivative_one_byte(M, N, K, pad):
                    aux=aux, ldaux=136, act=ops.ACT_QUICK_GELU, aux_kind=2)
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(16384, 1536, 384, 0), (16384 + 128, 1536, 384, 512), (32768, 768, 128, 0)])
+def test_gemm_saved_derivative_one_byte_erf_gelu(M, N, K, pad):
+    """aux_kind 2 with the erf-GELU of the MAE decoders (round 6; modules/module_mae.py:110-134 = timm Block with nn.GELU): the 256 x 256-
+    tile GEMM evaluates erf by Abramowitz-Stegun 7.1.26 in its epilogue and stores act'(u) = Phi(u) + u phi(u) as one byte; the data
+    gradient multiplies by the decoded byte.  Ragged shapes fall back to the saved pre-activation (aux_kind 0)."""
+    x, w, b = rnd(M, K, dtype=BF, seed=66), rnd(N, K, dtype=BF, seed=67, scale=K ** -0.5), rnd(N, seed=68)
+    pre = x.float() @ w.float().t() + b
+    yref = torch.nn.functional.gelu(pre)
+    cdf = 0.5 * (1 + torch.erf(pre * 2 ** -0.5))
+    dref = cdf + pre * torch.exp(-0.5 * pre * pre) * (2 * math.pi) ** -0.5
+    y0, a0 = ops.p_linear(x, w, b, act=ops.ACT_GELU_ERF, want_aux=True, aux_kind=0)       # the 8-phase kernel, erff
+    y2, a2 = ops.p_linear(x, w, b, act=ops.ACT_GELU_ERF, want_aux=True, aux_kind=2, pitched=pad > 0)
+    assert a2.dtype == torch.uint8 and a2.shape == (M, N) and a0.dtype == BF
+    close(y2, yref, 2e-2, 2e-2, "erf-GELU forward")
+    close(y2, y0.float(), 1.6e-2, 1e-3, "both kernels' erf-GELU agree to a bf16 step")
+    dec = a2.float() / 204.0 - 0.125
+    # half a step + saturation of the two extremes (act' in [-0.129, 1.129], representable [-0.125, 1.125]) + the bf16 noise of pre
+    assert float((dec - dref).abs().max()) <= 0.5 / 204.0 + 0.0042 + 4e-3, float((dec - dref).abs().max())
+    g, w2 = rnd(M, K, dtype=BF, seed=69), rnd(K, N, dtype=BF, seed=70, scale=K ** -0.5)
+    du2, cs = ops.p_dgrad(g, w2, BF, aux=a2, act=ops.ACT_GELU_ERF, aux_kind=2, want_colsum=True, pitched=pad > 0)
+    close(du2, (g.float() @ w2.float()) * dec, 2e-2, 2e-2, "dgrad * decoded derivative")
+    close(cs, du2.float().sum(0), 2e-3, 2e-2 * M ** 0.5, "fused column sums")
+    du0 = ops.p_dgrad(g, w2, BF, aux=a0, act=ops.ACT_GELU_ERF, aux_kind=0)
+    close(du2, du0, 3e-2, 3e-2, "byte derivative against the recomputed one")
+    # ragged shapes, and problems too small for the 256 x 256-tile kernel (the other kernels' byte epilogue is QuickGELU's): the byte
+    # form is refused, p_linear keeps the pre-activation instead
+    for r, c in ((200, 136), (512, 512)):
+        y3, a3 = ops.p_linear(x[:r], w[:c], b[:c], act=ops.ACT_GELU_ERF, want_aux=True, aux_kind=2)
+        y4, a4 = ops.p_linear(x[:r], w[:c], b[:c], act=ops.ACT_GELU_ERF, want_aux=True, aux_kind=0)
+        assert a3.dtype == BF and torch.equal(a3, a4) and torch.equal(y3, y4)
+
+
 @pytest.mark.parametrize("K", [64, 128, 192, 448])
 def test_gemm_half_tile_tail_is_bit_identical(K):
     """gemm_bf16_pq.hip: a launch whose last round of 256 workgroups is at most half full runs those tiles as 128 x 256
